@@ -1,0 +1,176 @@
+/* rtamd.h — C ABI of the MI355X-native RTBase hot path (librtamd.so).
+ *
+ * The reference (charlescookey/RayTracer, "RTBase") has no plugin/FFI layer:
+ * its hot path sits behind four C++ seams inside one translation unit.  Each
+ * entry point below replaces one of those seams; the citation names the
+ * reference interface it stands in for (paths relative to RTBase/).
+ *
+ * Conventions: plain pointers and sizes, no C++ or torch types; every call
+ * returns RT_OK (0) or a negative rt_status and leaves a message retrievable
+ * with rt_last_error() (the reference itself only prints / exit(0)s).  Host
+ * buffers passed in are copied; the caller keeps ownership.  A scene is
+ * immutable after creation and may be traversed from several host threads;
+ * a renderer must be driven from one thread at a time (RayTracer::render is
+ * called serially from main, Main.cpp:119).  All device memory is owned by the
+ * opaque handles and lives on the HIP device current at creation time.
+ */
+#ifndef RTAMD_H
+#define RTAMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,   /* bad argument / inconsistent descriptor */
+    RT_ERR_DEVICE = -2,    /* HIP runtime error (message has hipGetErrorString) */
+    RT_ERR_NOMEM = -3,
+    RT_ERR_UNSUPPORTED = -4
+} rt_status;
+
+/* BSDF classes of Materials.h (DiffuseBSDF:199 MirrorBSDF:248 ConductorBSDF:294 GlassBSDF:434
+ * DielectricBSDF:530 OrenNayarBSDF:748 PlasticBSDF:842); LayeredBSDF:1008 is flag bit 0 on its base. */
+enum { RT_MAT_DIFFUSE = 0, RT_MAT_MIRROR, RT_MAT_CONDUCTOR, RT_MAT_GLASS, RT_MAT_DIELECTRIC, RT_MAT_ORENNAYAR, RT_MAT_PLASTIC };
+#define RT_MAT_FLAG_LAYERED 1u
+
+typedef struct {
+    uint32_t type;
+    int32_t albedo_tex;     /* index into rt_scene_desc.textures (solid colours are 1x1 textures, as upstream) */
+    uint32_t flags;
+    float emission[3];      /* BSDF::emission; isLight() <=> Lum(emission) > 0 (Materials.h:184) */
+    float int_ior, ext_ior;
+    float roughness;        /* alpha = 1.62142*sqrt(roughness) is derived inside (Materials.h:307) */
+    float eta[3], k[3];     /* conductor */
+    float sigma;            /* oren-nayar (evaluates as Lambert upstream, Materials.h:777) */
+} rt_material;
+
+typedef struct {
+    int32_t width, height;
+    const float* rgb;       /* width*height*3, row-major, as Texture::texels (Imaging.h:18) */
+    const float* alpha;     /* optional, NULL if absent */
+} rt_texture;
+
+typedef struct {
+    uint32_t kind;          /* 0 BackgroundColour (Lights.h:87), 1 EnvironmentMap (Lights.h:138) */
+    float colour[3];
+    int32_t env_tex;
+} rt_background;
+
+typedef struct {
+    float P[16];            /* projection, row-major (Matrix::perspective, Core.h:460) */
+    float V[16];            /* camera-to-world = lookAt().invert() (SceneLoader.h:251-252) */
+    int32_t width, height;
+} rt_camera;
+
+typedef struct {
+    const float* verts;             /* n_tris * 3 vertices * {p.xyz, normal.xyz, u, v} (Core.h:197 Vertex) */
+    const uint32_t* tri_material;   /* n_tris */
+    uint32_t n_tris;
+    const rt_material* materials;
+    uint32_t n_materials;
+    const rt_texture* textures;
+    uint32_t n_textures;
+    rt_background background;
+} rt_scene_desc;
+
+typedef struct { float o[3]; float d[3]; } rt_ray;          /* Ray::o, Ray::dir (Geometry.h:9-10); invDir is derived */
+typedef struct { float p1[3]; float p2[3]; } rt_segment;    /* arguments of Scene::visible */
+typedef struct { uint32_t ID; float t, alpha, beta, gamma; } rt_hit;  /* IntersectionData (Geometry.h:256); miss <=> t == FLT_MAX, ID = 0xFFFFFFFF */
+
+typedef struct {
+    uint32_t n_tris, n_lights;
+    uint32_t bvh2_nodes, bvh2_depth, bvh2_leaves, bvh2_max_leaf;   /* the reference-topology tree (Geometry.h:391) */
+    uint32_t wide_nodes, wide_max_stack;                           /* the flattened 4-wide tree the kernels walk */
+    uint64_t device_bytes;
+    float build_seconds;
+} rt_scene_info;
+
+typedef struct {
+    uint64_t closest_rays, any_rays;        /* rays issued (Scene::traverse / Scene::visible equivalents) */
+    uint64_t nodes_visited, tris_tested;    /* wide-node fetches (128 B each) and triangle-record fetches (64 B each) */
+    uint64_t exact_path_rays;               /* rays routed through the reference-order fallback walk */
+} rt_counters;
+
+typedef struct rt_scene rt_scene;
+typedef struct rt_renderer rt_renderer;
+
+const char* rt_last_error(void);
+/* HIP device count / selection; rt_device_set must precede handle creation on that thread. */
+int rt_device_count(void);
+int rt_device_set(int device);
+
+/* --- Scene::init + Scene::build (Scene.h:150, :92): Triangle::init precompute, reference-topology
+ * binned-SAH BVH (Geometry.h:310-438), light list (Scene.h:107-116), flatten + upload. */
+int rt_scene_create(const rt_scene_desc* desc, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+/* --- Camera::init + Camera::updateView (Scene.h:26, :37) */
+int rt_scene_set_camera(rt_scene* scene, const rt_camera* cam);
+int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
+/* DFS leaf order of the reference tree (triangle indices), for structural parity checks. */
+int rt_scene_leaf_order(const rt_scene* scene, uint32_t* out_n_tris);
+
+/* --- IntersectionData Scene::traverse(const Ray&) (Scene.h:118), batched.
+ * `mode`: 0 = 4-wide ordered walk (+ reference-order fallback for rays with a zero/denormal
+ * direction component), 1 = reference-order walk for every ray (validation).
+ * Host-buffer form copies in/out; the _dev form takes device pointers and a hipStream_t. */
+int rt_intersect_closest(rt_scene* scene, const rt_ray* rays, size_t n, rt_hit* out, int mode);
+int rt_intersect_closest_dev(rt_scene* scene, const rt_ray* d_rays, size_t n, rt_hit* d_out, int mode, void* stream);
+/* --- bool Scene::visible(const Vec3&, const Vec3&) (Scene.h:169), batched; out[i] = 1 if visible. */
+int rt_intersect_any(rt_scene* scene, const rt_segment* segs, size_t n, uint8_t* out, int mode);
+int rt_intersect_any_dev(rt_scene* scene, const rt_segment* d_segs, size_t n, uint8_t* d_out, int mode, void* stream);
+/* --- Ray Camera::generateRay(float x, float y) (Scene.h:47), batched: xy[n][2] -> rays */
+int rt_generate_rays(rt_scene* scene, const float* xy, size_t n, rt_ray* out);
+/* Traversal counters accumulated since the last reset (only counted when enabled: costs atomics). */
+int rt_counters_enable(rt_scene* scene, int enable);
+int rt_counters_read(rt_scene* scene, rt_counters* out, int reset);
+
+/* --- RayTracer (Renderer.h:29): init / render / clear / getSPP / film access.
+ * Render modes follow `int type` of RayTracer::render (Renderer.h:372-395). */
+enum {
+    RT_MODE_PATH = 0,        /* renderMT -> pathTrace (Renderer.h:397, :215) */
+    RT_MODE_LIGHT = 1,       /* renderSTLight -> lightTrace (Renderer.h:327, :695), atomic splats */
+    RT_MODE_MLT = 2,         /* renderSTMLT -> PSSMLTRender (Renderer.h:353, :1013) */
+    RT_MODE_RADIOSITY = 4,   /* renderMTRadiosity -> pathTraceRadiosity (Renderer.h:431, :910) */
+    RT_MODE_PATH_ST = 5,     /* renderST: same estimator as RT_MODE_PATH */
+    RT_MODE_AOV_ALBEDO = 10, /* albedo() (Renderer.h:272) */
+    RT_MODE_AOV_NORMAL = 11, /* viewNormals() (Renderer.h:287) */
+    RT_MODE_DIRECT = 12      /* direct() (Renderer.h:257) */
+};
+int rt_renderer_create(rt_scene* scene, rt_renderer** out);              /* RayTracer::init (Renderer.h:56) */
+void rt_renderer_destroy(rt_renderer* r);
+/* Adds `spp` samples per pixel (sample indices first_sample .. first_sample+spp-1 of RNG stream `seed`)
+ * to the film and increments SPP by spp: `spp` consecutive RayTracer::render() calls. */
+int rt_render(rt_renderer* r, int mode, int spp, uint64_t seed, uint64_t first_sample);
+int rt_film_clear(rt_renderer* r);                                        /* RayTracer::clear (Renderer.h:107) */
+int rt_film_spp(const rt_renderer* r);                                    /* RayTracer::getSPP (Renderer.h:652) */
+/* Un-normalised accumulation film (Film::film, Imaging.h:219) + SPP; rgb = width*height*3 floats. */
+int rt_film_read(rt_renderer* r, float* rgb, int* spp);
+/* Render into caller-owned device memory (width*height*3 floats), e.g. a torch tensor that is then
+ * all-reduced over RCCL; NULL re-binds the internal film. */
+int rt_film_bind(rt_renderer* r, float* d_film);
+int rt_film_set_spp(rt_renderer* r, int spp);                             /* after an external film all-reduce */
+/* RayTracer::traceVPLs (Renderer.h:772); explicit because upstream never calls it (Renderer.h:68). */
+int rt_vpl_trace(rt_renderer* r, int n_vpls, uint64_t seed);
+int rt_vpl_count(const rt_renderer* r);
+/* Rays issued / node + triangle fetches by rt_render since the last reset. */
+int rt_render_counters(rt_renderer* r, rt_counters* out, int reset);
+int rt_renderer_sync(rt_renderer* r);
+/* Film::save (Imaging.h:278): Radiance .hdr of film/SPP; Film::tonemap (Imaging.h:251) to 8-bit RGB. */
+int rt_film_save_hdr(rt_renderer* r, const char* filename);
+int rt_film_tonemap(rt_renderer* r, uint8_t* rgb8);
+
+/* --- debug probes used by the parity tests: evaluate BSDF::sample / evaluate+PDF on the device for
+ * arrays of inputs (wo, shading normal, uv, rng key/counter). */
+int rt_debug_bsdf_sample(rt_scene* scene, uint32_t material, const float* wo, const float* n, const float* uv,
+                         const uint32_t* rng_key_ctr, size_t count, float* out7);
+int rt_debug_bsdf_eval(rt_scene* scene, uint32_t material, const float* wo, const float* n, const float* uv,
+                       const float* wi, size_t count, float* out4);
+int rt_debug_rng(uint64_t seed, uint64_t sample, uint32_t pixel, uint32_t stream, int n, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTAMD_H */

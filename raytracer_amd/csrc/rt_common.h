@@ -1,0 +1,96 @@
+// rt_common.h — data layouts shared by the host builder and the gfx950 kernels.
+//
+// HBM layout (all arrays live for the lifetime of an rt_scene):
+//   tris     : 64 B / triangle, 64-B aligned, stored in the DFS leaf order of the
+//              reference tree, so "first visited wins ties" (Geometry.h:449) becomes
+//              "lowest index wins".  One lane fetches one record as 4 x dwordx4.
+//   trishade : 64 B / triangle (vertex normals, uvs, area), same order; only read at a hit.
+//   nodes4   : 128 B (one L2 line) per 4-wide node: SoA child boxes + child refs.
+//   nodes2   : 48 B per node of the reference-topology binary tree (validation / fallback walk).
+#pragma once
+#include <stdint.h>
+
+#define RT_EPSILON 0.001f   // Geometry.h:49
+#define RT_MAX_DEPTH 4      // Renderer.h:18
+
+// child reference encoding of the 4-wide tree
+#define RT_REF_EMPTY 0xFFFFFFFFu
+#define RT_REF_LEAF 0x80000000u
+#define RT_LEAF_MAX 16u
+#define RT_LEAF_FIRST_MASK 0x07FFFFFFu
+static inline uint32_t rt_make_leaf_ref(uint32_t first, uint32_t count) { return RT_REF_LEAF | ((count - 1u) << 27) | first; }
+
+struct DTri {        // intersection record (Triangle::rayIntersect reads n, d, e1, e2, v1, v2: Geometry.h:115-128)
+    float v0[3], v1[3], v2[3];
+    float n[3];
+    float d;
+    float inv_area;  // 1.0f / Dot(e1.cross(e2), n), hoisted out of the per-ray call (same float ops, same bits)
+    uint32_t orig_id;   // index in the caller's triangle array (== triangleMap[tri], Geometry.h:454)
+    uint32_t mat_gsign; // material index | (gNormal flipped ? 1u<<31 : 0)   (Geometry.h:175)
+};
+struct DTriShade {   // shading record (Triangle::interpolateAttributes / sample, Geometry.h:154-174)
+    float n0[3], n1[3], n2[3];
+    float uv[6];
+    float area;
+};
+struct DNode4 {      // 128 B
+    float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+    uint32_t child[4];
+    uint32_t pad[4];
+};
+struct DNode2 {      // 48 B, reference-topology node (BVHNode, Geometry.h:290): leaf <=> left < 0 && right < 0
+    float lo[3]; int32_t left;
+    float hi[3]; int32_t right;
+    int32_t first, count, pad0, pad1;
+};
+static_assert(sizeof(DTri) == 64 && sizeof(DTriShade) == 64 && sizeof(DNode4) == 128 && sizeof(DNode2) == 48, "layout");
+
+struct DMaterial {   // 80 B
+    uint32_t type;       // RT_MAT_*
+    int32_t tex;
+    uint32_t flags;      // bit0 two-sided, bit1 pure specular, bit2 is light
+    float alpha;         // 1.62142f * sqrtf(roughness)
+    float emission[3];
+    float int_ior;
+    float ext_ior;
+    float eta[3];
+    float k[3];
+    float phong_e;       // PlasticBSDF::alphaToPhongExponent (Materials.h:857)
+    float pad[3];
+};
+#define RT_MF_TWOSIDED 1u
+#define RT_MF_SPECULAR 2u
+#define RT_MF_LIGHT 4u
+
+struct DTexture { uint32_t offset; int32_t width, height; int32_t pad; };  // offset in floats into the texel pool
+
+struct DLight { uint32_t kind; uint32_t tri; };  // kind 0 area (tri = DFS rank), 1 background colour, 2 environment map
+
+struct DCamera {     // Camera (Scene.h:14-45)
+    float P[16], invP[16], cam[16], cam2view[16];
+    float width, height;
+    float origin[3], view_dir[3];
+    float Afilm;
+    int32_t iw, ih;
+};
+
+struct DScene {
+    const DTri* tris;
+    const DTriShade* trishade;
+    const DNode4* nodes4;
+    const DNode2* nodes2;
+    const DMaterial* mats;
+    const DTexture* tex;
+    const float* texels;
+    const DLight* lights;
+    uint32_t n_tris, n_lights, n_nodes4, n_nodes2;
+    uint32_t root_ref;        // RT_REF_EMPTY for an empty scene, else node 0
+    uint32_t max_stack4, max_stack2;
+    float abs_max;            // max |coordinate| over the scene, scales the conservative cull pad
+    float bg_colour[3];
+    uint32_t bg_kind; int32_t bg_tex;
+    float scene_centre[3], scene_radius;   // SceneBounds (Lights.h:12, SceneLoader.h:286-287)
+    DCamera cam;
+};
+
+struct DCounters { unsigned long long closest, any, nodes, tris, exact; };

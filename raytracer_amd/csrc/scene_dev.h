@@ -1,0 +1,43 @@
+// scene_dev.h — the opaque rt_scene / error plumbing shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rtamd.h"
+#include "rt_common.h"
+#include "scene_build.h"
+
+void rt_set_error(const std::string& msg);
+int rt_hip_fail(hipError_t e, const char* what);
+#define RT_HIP(call)                                             \
+    do {                                                         \
+        hipError_t e_ = (call);                                  \
+        if (e_ != hipSuccess) return rt_hip_fail(e_, #call);     \
+    } while (0)
+
+// Launch geometry of the persistent traversal kernels: enough 256-thread blocks to fill every CU at the
+// occupancy the kernel's registers/LDS allow; waves then pull 64-ray chunks from a work counter.
+struct LaunchCfg { int blocks = 0; int threads = 0; };
+
+struct rt_scene {
+    int device = 0;
+    HostScene host;          // kept for info/leaf-order queries (device arrays are the copies the kernels read)
+    DScene d{};              // device pointers + scalars, passed to kernels by value
+    bool has_camera = false;
+    std::vector<void*> allocs;
+    uint64_t device_bytes = 0;
+    // per-scene scratch for the batched intersect entry points
+    DCounters* d_counters = nullptr;
+    unsigned long long* d_work = nullptr;   // work-fetch counters
+    uint32_t* d_spill4 = nullptr;           // overflow of the LDS stack (wide walk), may be null
+    uint32_t* d_spill2 = nullptr;           // stack of the reference-order walk
+    int persistent_blocks = 0;
+    bool count_enabled = false;
+    std::mutex mu;
+};
+
+// shared launch helpers (intersect.hip)
+int rt_scene_persistent_blocks(const rt_scene* s);
