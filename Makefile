@@ -1,0 +1,18 @@
+# Builds the product library (HIP, gfx950) and the test-infrastructure oracle.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CSRC = raytracer_amd/csrc
+SRCS = $(CSRC)/scene_build.cpp $(CSRC)/intersect.hip $(wildcard $(CSRC)/render.hip)
+HDRS = $(wildcard $(CSRC)/*.h) include/rtamd.h
+# -ffp-contract=off: the intersector must round like the reference's scalar code (bit-exact triangle IDs)
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wall -Wno-unused-function
+
+all: product oracle
+product: raytracer_amd/librtamd.so
+raytracer_amd/librtamd.so: $(SRCS) $(HDRS)
+	$(HIPCC) $(HIPFLAGS) $(SRCS) -o $@
+oracle:
+	$(MAKE) -C oracle
+clean:
+	rm -f raytracer_amd/librtamd.so oracle/liboracle.so
+.PHONY: all product oracle clean

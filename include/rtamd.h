@@ -111,6 +111,9 @@ int rt_scene_set_camera(rt_scene* scene, const rt_camera* cam);
 int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
 /* DFS leaf order of the reference tree (triangle indices), for structural parity checks. */
 int rt_scene_leaf_order(const rt_scene* scene, uint32_t* out_n_tris);
+/* Host-only structure query: runs the same builder without touching a device (leaf_order/info may be NULL).
+ * Not a compute path: nothing can be traversed or rendered without a GPU. */
+int rt_host_build_info(const rt_scene_desc* desc, uint32_t* leaf_order, rt_scene_info* info);
 
 /* --- IntersectionData Scene::traverse(const Ray&) (Scene.h:118), batched.
  * `mode`: 0 = 4-wide ordered walk (+ reference-order fallback for rays with a zero/denormal

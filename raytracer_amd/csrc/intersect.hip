@@ -1,0 +1,350 @@
+// intersect.hip — rt_scene lifetime + the batched Scene::traverse / Scene::visible entry points.
+//
+// Kernels are persistent: a fixed grid (CUs x resident blocks) of 256-thread blocks; each wave pulls
+// 64-ray chunks from a device work counter until the batch is drained, so a wave that finishes a cheap
+// chunk immediately takes more work and ray order (hence BVH/L2 locality of neighbouring rays) is kept.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include "rt_device.h"
+#include "scene_dev.h"
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+void rt_set_error(const std::string& msg) { g_err = msg; }
+int rt_hip_fail(hipError_t e, const char* what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return RT_ERR_DEVICE;
+}
+extern "C" const char* rt_last_error(void) { return g_err.c_str(); }
+extern "C" int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+extern "C" int rt_device_set(int device) {
+    RT_HIP(hipSetDevice(device));
+    return RT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ kernels
+__device__ __forceinline__ unsigned long long rt_fetch_chunk(unsigned long long* work) {
+    unsigned long long base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(work, 64ULL);
+    // broadcast lane 0's value to the wave
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
+    unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_intersect_closest(DScene S, const float* __restrict__ rays, unsigned long long n,
+                                                                rt_hit* __restrict__ out, int mode, unsigned long long* work,
+                                                                uint32_t* spill4, uint32_t* spill2, DCounters* counters) {
+    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
+    TravStack st; st.lds = lds_stack + threadIdx.x; st.glob = spill4 ? spill4 + gtid : nullptr; st.gstride = gstride;
+    uint32_t cn = 0, ct = 0, cx = 0, cr = 0;
+    for (;;) {
+        unsigned long long base = rt_fetch_chunk(work);
+        if (base >= n) break;
+        unsigned long long i = base + (threadIdx.x & 63);
+        if (i < n) {
+            const float* r = rays + i * 6;
+            f3 o = mk3(r[0], r[1], r[2]), d = mk3(r[3], r[4], r[5]);
+            HitRec h;
+            rt_closest<COUNT>(S, o, d, mode, h, st, spill2 + gtid, gstride, cn, ct, cx);
+            rt_hit res;
+            if (h.t < RT_FLT_MAX) {
+                res.ID = S.tris[h.rank].orig_id; res.t = h.t; res.alpha = h.u; res.beta = h.v; res.gamma = 1.0f - (h.u + h.v);  // Geometry.h:450-454
+            } else { res.ID = 0xFFFFFFFFu; res.t = RT_FLT_MAX; res.alpha = res.beta = res.gamma = 0.0f; }
+            out[i] = res;
+            if (COUNT) cr++;
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&counters->closest, (unsigned long long)cr); atomicAdd(&counters->nodes, (unsigned long long)cn);
+        atomicAdd(&counters->tris, (unsigned long long)ct); atomicAdd(&counters->exact, (unsigned long long)cx);
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_intersect_any(DScene S, const float* __restrict__ segs, unsigned long long n,
+                                                            uint8_t* __restrict__ out, int mode, unsigned long long* work,
+                                                            uint32_t* spill4, uint32_t* spill2, DCounters* counters) {
+    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
+    TravStack st; st.lds = lds_stack + threadIdx.x; st.glob = spill4 ? spill4 + gtid : nullptr; st.gstride = gstride;
+    uint32_t cn = 0, ct = 0, cx = 0, cr = 0;
+    for (;;) {
+        unsigned long long base = rt_fetch_chunk(work);
+        if (base >= n) break;
+        unsigned long long i = base + (threadIdx.x & 63);
+        if (i < n) {
+            const float* q = segs + i * 6;
+            bool vis = rt_visible<COUNT>(S, mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), mode, st, spill2 + gtid, gstride, cn, ct, cx);
+            out[i] = vis ? 1 : 0;
+            if (COUNT) cr++;
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&counters->any, (unsigned long long)cr); atomicAdd(&counters->nodes, (unsigned long long)cn);
+        atomicAdd(&counters->tris, (unsigned long long)ct); atomicAdd(&counters->exact, (unsigned long long)cx);
+    }
+}
+
+// Camera::generateRay (Scene.h:47-64)
+__device__ __forceinline__ f3 rt_mul_point_div(const float* m, f3 v) {  // Core.h:310
+    f3 a = mk3((v.x * m[0] + v.y * m[1] + v.z * m[2]) + m[3], (v.x * m[4] + v.y * m[5] + v.z * m[6]) + m[7],
+               (v.x * m[8] + v.y * m[9] + v.z * m[10]) + m[11]);
+    float w = (m[12] * v.x) + (m[13] * v.y) + (m[14] * v.z) + m[15];
+    w = 1.0f / w;
+    return a * w;
+}
+__global__ void k_generate_rays(DScene S, const float* __restrict__ xy, size_t n, float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DCamera& c = S.cam;
+    float x = xy[i * 2], y = xy[i * 2 + 1];
+    float xc = ((2 * x) / (c.width - 1)) - 1;
+    float yc = 1 - ((2 * y) / (c.height - 1));
+    f3 pcam = rt_mul_point_div(c.invP, mk3(xc, yc, 0));
+    f3 dcam = rt_mul_point_div(c.cam, pcam);
+    f3 org = ld3(c.origin);
+    f3 dir = dcam - org;
+    float* r = out + i * 6;
+    r[0] = org.x; r[1] = org.y; r[2] = org.z; r[3] = dir.x; r[4] = dir.y; r[5] = dir.z;
+}
+
+// ------------------------------------------------------------------------------------------------ scene
+template <class T>
+static int upload(rt_scene* s, const std::vector<T>& v, const T** dst) {
+    size_t bytes = sizeof(T) * std::max<size_t>(v.size(), 1);
+    void* p = nullptr;
+    RT_HIP(hipMalloc(&p, bytes));
+    s->allocs.push_back(p);
+    s->device_bytes += bytes;
+    if (!v.empty()) RT_HIP(hipMemcpy(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+    *dst = (const T*)p;
+    return RT_OK;
+}
+
+int rt_scene_persistent_blocks(const rt_scene* s) { return s->persistent_blocks; }
+
+extern "C" int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
+    if (!desc || !out) { rt_set_error("rt_scene_create: NULL argument"); return RT_ERR_INVALID; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        rt_set_error("rt_scene_create: no HIP device visible (this library has no CPU path)");
+        return RT_ERR_DEVICE;
+    }
+    rt_scene* s = new rt_scene();
+    std::string err;
+    if (!host_scene_build(*desc, s->host, err)) { rt_set_error("rt_scene_create: " + err); delete s; return RT_ERR_INVALID; }
+    int rc = RT_OK;
+    auto fail = [&](int code) { rt_scene_destroy(s); return code; };
+    if (hipGetDevice(&s->device) != hipSuccess) return fail(RT_ERR_DEVICE);
+    HostScene& h = s->host;
+    DScene& d = s->d;
+    if ((rc = upload(s, h.tris, &d.tris)) || (rc = upload(s, h.trishade, &d.trishade)) || (rc = upload(s, h.nodes4, &d.nodes4)) ||
+        (rc = upload(s, h.nodes2, &d.nodes2)) || (rc = upload(s, h.mats, &d.mats)) || (rc = upload(s, h.tex, &d.tex)) ||
+        (rc = upload(s, h.texels, &d.texels)) || (rc = upload(s, h.lights, &d.lights)))
+        return fail(rc);
+    d.n_tris = (uint32_t)h.tris.size(); d.n_lights = (uint32_t)h.lights.size();
+    d.n_nodes4 = (uint32_t)h.nodes4.size(); d.n_nodes2 = (uint32_t)h.nodes2.size();
+    d.root_ref = d.n_tris ? 0u : RT_REF_EMPTY;
+    d.max_stack4 = h.max_stack4; d.max_stack2 = h.max_stack2;
+    d.abs_max = h.abs_max;
+    memcpy(d.bg_colour, h.bg_colour, 12); d.bg_kind = h.bg_kind; d.bg_tex = h.bg_tex;
+    memcpy(d.scene_centre, h.centre, 12); d.scene_radius = h.radius;
+
+    // persistent launch geometry + traversal scratch
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, s->device) != hipSuccess) return fail(RT_ERR_DEVICE);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_intersect_closest<false>, RT_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (per_cu > 8) per_cu = 8;
+    s->persistent_blocks = prop.multiProcessorCount * per_cu;
+    size_t threads = (size_t)s->persistent_blocks * RT_BLOCK;
+    void* p = nullptr;
+    if (h.max_stack4 > RT_STACK_LDS) {
+        size_t bytes = threads * (h.max_stack4 - RT_STACK_LDS) * sizeof(uint32_t);
+        if (hipMalloc(&p, bytes) != hipSuccess) { rt_set_error("rt_scene_create: out of device memory (stack spill)"); return fail(RT_ERR_NOMEM); }
+        s->allocs.push_back(p); s->device_bytes += bytes; s->d_spill4 = (uint32_t*)p;
+    }
+    {
+        size_t bytes = threads * std::max<uint32_t>(h.max_stack2, 2) * sizeof(uint32_t);
+        if (hipMalloc(&p, bytes) != hipSuccess) { rt_set_error("rt_scene_create: out of device memory (reference-walk stack)"); return fail(RT_ERR_NOMEM); }
+        s->allocs.push_back(p); s->device_bytes += bytes; s->d_spill2 = (uint32_t*)p;
+    }
+    if (hipMalloc(&p, sizeof(DCounters)) != hipSuccess) return fail(RT_ERR_NOMEM);
+    s->allocs.push_back(p); s->d_counters = (DCounters*)p;
+    if (hipMemset(p, 0, sizeof(DCounters)) != hipSuccess) return fail(RT_ERR_DEVICE);
+    if (hipMalloc(&p, 256) != hipSuccess) return fail(RT_ERR_NOMEM);
+    s->allocs.push_back(p); s->d_work = (unsigned long long*)p;
+    *out = s;
+    return RT_OK;
+}
+
+extern "C" void rt_scene_destroy(rt_scene* s) {
+    if (!s) return;
+    for (void* p : s->allocs) (void)hipFree(p);
+    delete s;
+}
+
+extern "C" int rt_scene_set_camera(rt_scene* s, const rt_camera* cam) {
+    if (!s || !cam) { rt_set_error("rt_scene_set_camera: NULL argument"); return RT_ERR_INVALID; }
+    if (cam->width < 2 || cam->height < 2) { rt_set_error("rt_scene_set_camera: width/height must be >= 2"); return RT_ERR_INVALID; }
+    host_camera_build(*cam, s->d.cam);
+    s->has_camera = true;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_get_info(const rt_scene* s, rt_scene_info* o) {
+    if (!s || !o) { rt_set_error("rt_scene_get_info: NULL argument"); return RT_ERR_INVALID; }
+    const HostScene& h = s->host;
+    o->n_tris = (uint32_t)h.tris.size(); o->n_lights = (uint32_t)h.lights.size();
+    o->bvh2_nodes = (uint32_t)h.nodes2.size(); o->bvh2_depth = h.depth2; o->bvh2_leaves = h.leaves2; o->bvh2_max_leaf = h.max_leaf2;
+    o->wide_nodes = (uint32_t)h.nodes4.size(); o->wide_max_stack = h.max_stack4;
+    o->device_bytes = s->device_bytes; o->build_seconds = (float)h.build_seconds;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_leaf_order(const rt_scene* s, uint32_t* out) {
+    if (!s || !out) { rt_set_error("rt_scene_leaf_order: NULL argument"); return RT_ERR_INVALID; }
+    memcpy(out, s->host.leaf_order.data(), s->host.leaf_order.size() * sizeof(uint32_t));
+    return RT_OK;
+}
+
+// Host-only structure query (no device needed): lets CPU-side tests check the builder against the oracle.
+extern "C" int rt_host_build_info(const rt_scene_desc* desc, uint32_t* leaf_order, rt_scene_info* info) {
+    if (!desc) { rt_set_error("rt_host_build_info: NULL argument"); return RT_ERR_INVALID; }
+    HostScene h; std::string err;
+    if (!host_scene_build(*desc, h, err)) { rt_set_error("rt_host_build_info: " + err); return RT_ERR_INVALID; }
+    if (leaf_order) memcpy(leaf_order, h.leaf_order.data(), h.leaf_order.size() * sizeof(uint32_t));
+    if (info) {
+        memset(info, 0, sizeof(*info));
+        info->n_tris = (uint32_t)h.tris.size(); info->n_lights = (uint32_t)h.lights.size();
+        info->bvh2_nodes = (uint32_t)h.nodes2.size(); info->bvh2_depth = h.depth2; info->bvh2_leaves = h.leaves2; info->bvh2_max_leaf = h.max_leaf2;
+        info->wide_nodes = (uint32_t)h.nodes4.size(); info->wide_max_stack = h.max_stack4; info->build_seconds = (float)h.build_seconds;
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_counters_enable(rt_scene* s, int enable) {
+    if (!s) { rt_set_error("rt_counters_enable: NULL scene"); return RT_ERR_INVALID; }
+    s->count_enabled = enable != 0;
+    return RT_OK;
+}
+extern "C" int rt_counters_read(rt_scene* s, rt_counters* o, int reset) {
+    if (!s || !o) { rt_set_error("rt_counters_read: NULL argument"); return RT_ERR_INVALID; }
+    DCounters c;
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpy(&c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    o->closest_rays = c.closest; o->any_rays = c.any; o->nodes_visited = c.nodes; o->tris_tested = c.tris; o->exact_path_rays = c.exact;
+    if (reset) RT_HIP(hipMemset(s->d_counters, 0, sizeof(DCounters)));
+    return RT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ batched intersect
+static int check_mode(int mode) {
+    if (mode == 0 || mode == 1) return RT_OK;
+    rt_set_error("intersect: mode must be 0 (wide walk) or 1 (reference-order walk)");
+    return RT_ERR_INVALID;
+}
+
+extern "C" int rt_intersect_closest_dev(rt_scene* s, const rt_ray* d_rays, size_t n, rt_hit* d_out, int mode, void* stream) {
+    if (!s || (n && (!d_rays || !d_out))) { rt_set_error("rt_intersect_closest_dev: NULL argument"); return RT_ERR_INVALID; }
+    if (check_mode(mode)) return RT_ERR_INVALID;
+    if (n == 0) return RT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(s->mu);  // the work counter and the stack spill are per scene
+    RT_HIP(hipMemsetAsync(s->d_work, 0, sizeof(unsigned long long), st));
+    int blocks = (int)std::min<size_t>((n + RT_BLOCK - 1) / RT_BLOCK, (size_t)s->persistent_blocks);
+    if (s->count_enabled)
+        hipLaunchKernelGGL(k_intersect_closest<true>, dim3(blocks), dim3(RT_BLOCK), 0, st, s->d, (const float*)d_rays, (unsigned long long)n, d_out,
+                           mode, s->d_work, s->d_spill4, s->d_spill2, s->d_counters);
+    else
+        hipLaunchKernelGGL(k_intersect_closest<false>, dim3(blocks), dim3(RT_BLOCK), 0, st, s->d, (const float*)d_rays, (unsigned long long)n, d_out,
+                           mode, s->d_work, s->d_spill4, s->d_spill2, s->d_counters);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+extern "C" int rt_intersect_any_dev(rt_scene* s, const rt_segment* d_segs, size_t n, uint8_t* d_out, int mode, void* stream) {
+    if (!s || (n && (!d_segs || !d_out))) { rt_set_error("rt_intersect_any_dev: NULL argument"); return RT_ERR_INVALID; }
+    if (check_mode(mode)) return RT_ERR_INVALID;
+    if (n == 0) return RT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(s->mu);
+    RT_HIP(hipMemsetAsync(s->d_work, 0, sizeof(unsigned long long), st));
+    int blocks = (int)std::min<size_t>((n + RT_BLOCK - 1) / RT_BLOCK, (size_t)s->persistent_blocks);
+    if (s->count_enabled)
+        hipLaunchKernelGGL(k_intersect_any<true>, dim3(blocks), dim3(RT_BLOCK), 0, st, s->d, (const float*)d_segs, (unsigned long long)n, d_out, mode,
+                           s->d_work, s->d_spill4, s->d_spill2, s->d_counters);
+    else
+        hipLaunchKernelGGL(k_intersect_any<false>, dim3(blocks), dim3(RT_BLOCK), 0, st, s->d, (const float*)d_segs, (unsigned long long)n, d_out, mode,
+                           s->d_work, s->d_spill4, s->d_spill2, s->d_counters);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
+extern "C" int rt_intersect_closest(rt_scene* s, const rt_ray* rays, size_t n, rt_hit* out, int mode) {
+    if (!s || (n && (!rays || !out))) { rt_set_error("rt_intersect_closest: NULL argument"); return RT_ERR_INVALID; }
+    if (check_mode(mode)) return RT_ERR_INVALID;
+    if (n == 0) return RT_OK;
+    DevBuf in, o;
+    RT_HIP(hipMalloc(&in.p, n * sizeof(rt_ray)));
+    RT_HIP(hipMalloc(&o.p, n * sizeof(rt_hit)));
+    RT_HIP(hipMemcpy(in.p, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
+    int rc = rt_intersect_closest_dev(s, (const rt_ray*)in.p, n, (rt_hit*)o.p, mode, nullptr);
+    if (rc) return rc;
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpy(out, o.p, n * sizeof(rt_hit), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_intersect_any(rt_scene* s, const rt_segment* segs, size_t n, uint8_t* out, int mode) {
+    if (!s || (n && (!segs || !out))) { rt_set_error("rt_intersect_any: NULL argument"); return RT_ERR_INVALID; }
+    if (check_mode(mode)) return RT_ERR_INVALID;
+    if (n == 0) return RT_OK;
+    DevBuf in, o;
+    RT_HIP(hipMalloc(&in.p, n * sizeof(rt_segment)));
+    RT_HIP(hipMalloc(&o.p, n));
+    RT_HIP(hipMemcpy(in.p, segs, n * sizeof(rt_segment), hipMemcpyHostToDevice));
+    int rc = rt_intersect_any_dev(s, (const rt_segment*)in.p, n, (uint8_t*)o.p, mode, nullptr);
+    if (rc) return rc;
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpy(out, o.p, n, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_generate_rays(rt_scene* s, const float* xy, size_t n, rt_ray* out) {
+    if (!s || (n && (!xy || !out))) { rt_set_error("rt_generate_rays: NULL argument"); return RT_ERR_INVALID; }
+    if (!s->has_camera) { rt_set_error("rt_generate_rays: no camera set"); return RT_ERR_INVALID; }
+    if (n == 0) return RT_OK;
+    DevBuf in, o;
+    RT_HIP(hipMalloc(&in.p, n * 8));
+    RT_HIP(hipMalloc(&o.p, n * sizeof(rt_ray)));
+    RT_HIP(hipMemcpy(in.p, xy, n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_generate_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, s->d, (const float*)in.p, n, (float*)o.p);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpy(out, o.p, n * sizeof(rt_ray), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_debug_rng(uint64_t seed, uint64_t sample, uint32_t pixel, uint32_t stream, int n, float* out) {
+    if (!out || n < 0) { rt_set_error("rt_debug_rng: bad argument"); return RT_ERR_INVALID; }
+    Rng r; r.key = rt_rng_key(seed, sample, pixel, stream); r.ctr = 0;
+    for (int i = 0; i < n; i++) out[i] = rt_rng_next(r);
+    return RT_OK;
+}
