@@ -56,6 +56,18 @@ SYMBOLS = [
 ]
 
 
+def _sig(L, name, argtypes=None, restype=None, set_restype=False):
+    # a symbol missing from a stale build surfaces as AttributeError at call time (and in tests/test_abi.py)
+    try:
+        f = getattr(L, name)
+    except AttributeError:
+        return
+    if argtypes is not None:
+        f.argtypes = argtypes
+    if set_restype:
+        f.restype = restype
+
+
 def lib():
     """Loads librtamd.so; raises loudly when the HIP extension has not been built."""
     global _lib
@@ -64,40 +76,40 @@ def lib():
             raise RtError(f"{LIB_PATH} not found: build it with `make product` (hipcc --offload-arch=gfx950). "
                           "raytracer_amd has no CPU fallback.")
         L = C.CDLL(LIB_PATH)
-        L.rt_last_error.restype = C.c_char_p
+        _sig(L, "rt_last_error", None, C.c_char_p, True)
         vp, sz, i32, u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64
-        L.rt_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(vp)]
-        L.rt_scene_destroy.argtypes = [vp]
-        L.rt_scene_destroy.restype = None
-        L.rt_scene_set_camera.argtypes = [vp, C.POINTER(Camera)]
-        L.rt_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
-        L.rt_scene_leaf_order.argtypes = [vp, vp]
-        L.rt_host_build_info.argtypes = [C.POINTER(SceneDesc), vp, C.POINTER(SceneInfo)]
-        L.rt_intersect_closest.argtypes = [vp, vp, sz, vp, i32]
-        L.rt_intersect_closest_dev.argtypes = [vp, vp, sz, vp, i32, vp]
-        L.rt_intersect_any.argtypes = [vp, vp, sz, vp, i32]
-        L.rt_intersect_any_dev.argtypes = [vp, vp, sz, vp, i32, vp]
-        L.rt_generate_rays.argtypes = [vp, vp, sz, vp]
-        L.rt_counters_enable.argtypes = [vp, i32]
-        L.rt_counters_read.argtypes = [vp, C.POINTER(Counters), i32]
-        L.rt_renderer_create.argtypes = [vp, C.POINTER(vp)]
-        L.rt_renderer_destroy.argtypes = [vp]
-        L.rt_renderer_destroy.restype = None
-        L.rt_render.argtypes = [vp, i32, i32, u64, u64]
-        L.rt_film_clear.argtypes = [vp]
-        L.rt_film_spp.argtypes = [vp]
-        L.rt_film_read.argtypes = [vp, vp, C.POINTER(i32)]
-        L.rt_film_bind.argtypes = [vp, vp]
-        L.rt_film_set_spp.argtypes = [vp, i32]
-        L.rt_vpl_trace.argtypes = [vp, i32, u64]
-        L.rt_vpl_count.argtypes = [vp]
-        L.rt_render_counters.argtypes = [vp, C.POINTER(Counters), i32]
-        L.rt_renderer_sync.argtypes = [vp]
-        L.rt_film_save_hdr.argtypes = [vp, C.c_char_p]
-        L.rt_film_tonemap.argtypes = [vp, vp]
-        L.rt_debug_bsdf_sample.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, sz, vp]
-        L.rt_debug_bsdf_eval.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, sz, vp]
-        L.rt_debug_rng.argtypes = [u64, u64, C.c_uint32, C.c_uint32, i32, vp]
+        _sig(L, "rt_scene_create", [C.POINTER(SceneDesc), C.POINTER(vp)])
+        _sig(L, "rt_scene_destroy", [vp])
+        _sig(L, "rt_scene_destroy", None, None, True)
+        _sig(L, "rt_scene_set_camera", [vp, C.POINTER(Camera)])
+        _sig(L, "rt_scene_get_info", [vp, C.POINTER(SceneInfo)])
+        _sig(L, "rt_scene_leaf_order", [vp, vp])
+        _sig(L, "rt_host_build_info", [C.POINTER(SceneDesc), vp, C.POINTER(SceneInfo)])
+        _sig(L, "rt_intersect_closest", [vp, vp, sz, vp, i32])
+        _sig(L, "rt_intersect_closest_dev", [vp, vp, sz, vp, i32, vp])
+        _sig(L, "rt_intersect_any", [vp, vp, sz, vp, i32])
+        _sig(L, "rt_intersect_any_dev", [vp, vp, sz, vp, i32, vp])
+        _sig(L, "rt_generate_rays", [vp, vp, sz, vp])
+        _sig(L, "rt_counters_enable", [vp, i32])
+        _sig(L, "rt_counters_read", [vp, C.POINTER(Counters), i32])
+        _sig(L, "rt_renderer_create", [vp, C.POINTER(vp)])
+        _sig(L, "rt_renderer_destroy", [vp])
+        _sig(L, "rt_renderer_destroy", None, None, True)
+        _sig(L, "rt_render", [vp, i32, i32, u64, u64])
+        _sig(L, "rt_film_clear", [vp])
+        _sig(L, "rt_film_spp", [vp])
+        _sig(L, "rt_film_read", [vp, vp, C.POINTER(i32)])
+        _sig(L, "rt_film_bind", [vp, vp])
+        _sig(L, "rt_film_set_spp", [vp, i32])
+        _sig(L, "rt_vpl_trace", [vp, i32, u64])
+        _sig(L, "rt_vpl_count", [vp])
+        _sig(L, "rt_render_counters", [vp, C.POINTER(Counters), i32])
+        _sig(L, "rt_renderer_sync", [vp])
+        _sig(L, "rt_film_save_hdr", [vp, C.c_char_p])
+        _sig(L, "rt_film_tonemap", [vp, vp])
+        _sig(L, "rt_debug_bsdf_sample", [vp, C.c_uint32, vp, vp, vp, vp, sz, vp])
+        _sig(L, "rt_debug_bsdf_eval", [vp, C.c_uint32, vp, vp, vp, vp, sz, vp])
+        _sig(L, "rt_debug_rng", [u64, u64, C.c_uint32, C.c_uint32, i32, vp])
         _lib = L
     return _lib
 

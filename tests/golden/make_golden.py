@@ -1,0 +1,94 @@
+"""Generates tests/golden/*.npz from the COMPILED REFERENCE (oracle/_ref/libref_geom.so, i.e. the
+reference's own Geometry.h/Core.h/Sampling.h built by oracle/Makefile).  Run in a container that holds
+/root/reference:   python tests/golden/make_golden.py
+The fixtures are data only: seeded inputs (scene triangles, rays, segments) and the reference's outputs.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import orc  # noqa: E402
+from raytracer_amd import scenes  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def axis_rays(s, n, rng):
+    """Rays with exact-zero direction components and origins on vertex coordinates (NaN/inf slab cases)."""
+    v = s.verts[:, :, :3].reshape(-1, 3)
+    o = v[rng.integers(0, len(v), n)].astype(np.float32) + np.float32(0.0)
+    o[:, 1] += rng.choice([0.0, 0.5, 2.0], n).astype(np.float32)
+    d = np.zeros((n, 3), np.float32)
+    ax = rng.integers(0, 3, n)
+    d[np.arange(n), ax] = rng.choice([-1.0, 1.0], n)
+    two = rng.uniform(0, 1, n) < 0.4
+    d[two, (ax[two] + 1) % 3] = rng.uniform(-1, 1, two.sum()).astype(np.float32)
+    return np.concatenate([o, d], 1).astype(np.float32)
+
+
+def main():
+    cases = {
+        "cornell": scenes.cornell(256, 256),
+        "cornell_spec": scenes.cornell(256, 256, with_specular=True),
+        "soup": scenes.random_soup(3000, seed=5),
+        "lattice": scenes.axis_aligned_grid(6),
+        "bathroom_small": scenes.interior("bathroom", 0.06, 320, 180),
+    }
+    for name, s in cases.items():
+        r = orc.RefScene(s)
+        rng = np.random.default_rng(11)
+        n = 4096
+        rays = np.concatenate([scenes.primary_rays(s, n, 1), scenes.bounce_rays(s, n, 2), axis_rays(s, 1024, rng)])
+        segs = scenes.shadow_segments(s, n, 3)
+        hits = r.traverse(rays)
+        vis = r.visible(segs)
+        order, st = r.leaf_order()
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), verts=s.verts, tri_mat=s.tri_mat, rays=rays, segs=segs,
+                            hit_id=hits["ID"], hit_t=hits["t"], hit_alpha=hits["alpha"], hit_beta=hits["beta"], hit_gamma=hits["gamma"],
+                            visible=vis, leaf_order=order, stats=np.array([st["depth"], st["nodes"], st["leaves"]], np.int32))
+        print(name, s.ntris, "hits", int((hits["t"] < 3e38).sum()), "/", len(rays), "visible", float(vis.mean()), st)
+        r.close()
+    # scalar known-answer vectors of the reference's own unit tests (RTTest/RTTest.cpp:15-72), evaluated by the reference
+    L = orc.ref()
+    tri = np.array([0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0], np.float32)
+    ray = np.array([0.25, 0.25, 1.0, 0, 0, -1], np.float32)
+    out = {}
+    for which in (0, 2, 3):
+        tuv = np.zeros(3, np.float32)
+        hit = L.ref_tri_intersect(tri.ctypes.data, ray.ctypes.data, which, tuv.ctypes.data)
+        out[f"tri{which}"] = np.concatenate([[hit], tuv]).astype(np.float32)
+    t = np.zeros(1, np.float32)
+    pn = np.array([0, 1, 1], np.float32)
+    pr = np.array([0, 10, 0, 0, -1, 0], np.float32)
+    out["plane"] = np.array([L.ref_plane_intersect(pn.ctypes.data, 0.0, pr.ctypes.data, t.ctypes.data), t[0]], np.float32)
+    out["aabb_default_area"] = np.array([L.ref_aabb_default_area()], np.float32)
+    # sampling / frame / matrix tables
+    rng = np.random.default_rng(3)
+    r12 = rng.uniform(0, 1, (256, 2)).astype(np.float32)
+    samp = np.zeros((3, 256, 4), np.float32)
+    for w in range(3):
+        for i in range(256):
+            L.ref_sampling(w, float(r12[i, 0]), float(r12[i, 1]), samp[w, i].ctypes.data)
+    nv = rng.normal(size=(256, 2, 3)).astype(np.float32)
+    fr = np.zeros((256, 15), np.float32)
+    for i in range(256):
+        L.ref_frame(nv[i, 0].ctypes.data, nv[i, 1].ctypes.data, fr[i].ctypes.data)
+    mats = {}
+    pin = np.array([0.001, 10000.0, 16.0 / 9.0, 45.0], np.float32)
+    m = np.zeros(16, np.float32); L.ref_matrix(0, pin.ctypes.data, m.ctypes.data); mats["persp"] = m.copy()
+    lin = np.array([3.3, 1.65, 2.5, -1.2, 0.9, -0.9, 0, 1, 0], np.float32)
+    L.ref_matrix(1, lin.ctypes.data, m.ctypes.data); mats["lookat"] = m.copy()
+    inv = np.zeros(16, np.float32); L.ref_matrix(2, mats["lookat"].ctypes.data, inv.ctypes.data); mats["lookat_inv"] = inv.copy()
+    L.ref_matrix(2, mats["persp"].ctypes.data, inv.ctypes.data); mats["persp_inv"] = inv.copy()
+    mt = np.zeros(16, np.float32); L.ref_mtrandom(1, 16, mt.ctypes.data)
+    np.savez_compressed(os.path.join(HERE, "scalars.npz"), tri=tri, ray=ray, r12=r12, sampling=samp, frame_in=nv, frame_out=fr,
+                        persp_in=pin, lookat_in=lin, mtrandom_seed1=mt, **out, **mats)
+    print({k: v.tolist() for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,77 @@
+"""CPU: the oracle (oracle/rt_oracle.c) against fixtures produced by the compiled reference
+(tests/golden/make_golden.py) and against the reference's own unit-test vectors (RTTest/RTTest.cpp)."""
+import numpy as np
+import pytest
+
+import orc
+from util import GOLDEN, GOLDEN_SCENES, assert_hits_bitexact, bits, load_golden
+
+
+@pytest.mark.parametrize("name", GOLDEN_SCENES)
+def test_oracle_matches_reference_fixture(name):
+    s, g, want = load_golden(name)
+    o = orc.OracleScene(s)
+    assert (o.leaf_order() == g["leaf_order"]).all()
+    info = o.info()
+    assert [info["depth"], info["nodes"], info["leaves"]] == g["stats"].tolist()
+    assert_hits_bitexact(o.traverse(g["rays"]), want, name)
+    assert (o.visible(g["segs"]) == g["visible"]).all()
+    # UseBVH=false brute force (Scene.h:123) agrees with the tree on hit/miss wherever no box-rounding is in play:
+    # it may only ever find *more* hits than the tree (the tree can drop a hit on a box edge), never fewer.
+    b = o.traverse(g["rays"][:512], brute=True)
+    assert ((b["t"] < 3e38) | ~(want["t"][:512] < 3e38)).all()
+
+
+def test_rttest_vectors():
+    g = np.load(f"{GOLDEN}/scalars.npz")
+    L = orc.lib()
+    tuv = np.zeros(3, np.float32)
+    tri, ray = g["tri"], g["ray"]
+    hit = L.orc_tri_intersect(tri.ctypes.data, ray.ctypes.data, tuv.ctypes.data)
+    # RTTest.cpp:39 TestRayInterset, production intersector: hit, t=1, u=0.5 (weight of v0), v=0.25
+    assert hit == 1 and tuv.tolist() == [1.0, 0.5, 0.25]
+    assert g["tri0"].tolist() == [1.0, 1.0, 0.5, 0.25]
+    # RTTest.cpp:28 InfinteArea
+    assert np.isinf(L.orc_aabb_default_area()) and np.isinf(g["aabb_default_area"][0])
+    # RTTest.cpp:15 TestRayIntersect (plane n=(0,1,1) d=0, ray from (0,10,0) down): t = 10
+    assert g["plane"].tolist() == [1.0, 10.0]
+
+
+def test_sampling_frame_matrix_tables():
+    g = np.load(f"{GOLDEN}/scalars.npz")
+    L = orc.lib()
+    out = np.zeros(4, np.float32)
+    for w in range(3):
+        for i in range(256):
+            L.orc_sampling(w, float(g["r12"][i, 0]), float(g["r12"][i, 1]), out.ctypes.data)
+            assert (bits(out) == bits(g["sampling"][w, i])).all(), (w, i)
+    fr = np.zeros(15, np.float32)
+    for i in range(256):
+        n, v = np.ascontiguousarray(g["frame_in"][i, 0]), np.ascontiguousarray(g["frame_in"][i, 1])
+        L.orc_frame(n.ctypes.data, v.ctypes.data, fr.ctypes.data)
+        assert (bits(fr) == bits(g["frame_out"][i])).all()
+    m = np.zeros(16, np.float32)
+    L.orc_matrix(0, g["persp_in"].ctypes.data, m.ctypes.data)
+    assert (bits(m) == bits(g["persp"])).all()
+    L.orc_matrix(1, g["lookat_in"].ctypes.data, m.ctypes.data)
+    assert (bits(m) == bits(g["lookat"])).all()
+    L.orc_matrix(2, np.ascontiguousarray(g["lookat"]).ctypes.data, m.ctypes.data)
+    assert (bits(m) == bits(g["lookat_inv"])).all()
+    L.orc_matrix(2, np.ascontiguousarray(g["persp"]).ctypes.data, m.ctypes.data)
+    assert (bits(m) == bits(g["persp_inv"])).all()
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_oracle_vs_live_reference_build():
+    from raytracer_amd import scenes
+    from util import axis_rays
+    for s in (scenes.interior("living-room", 0.08, 160, 90), scenes.random_soup(2000, seed=9)):
+        o, r = orc.OracleScene(s), orc.RefScene(s)
+        assert (o.leaf_order() == r.leaf_order()[0]).all()
+        rays = np.concatenate([scenes.primary_rays(s, 3000, 4), scenes.bounce_rays(s, 3000, 5), axis_rays(s, 500)])
+        assert_hits_bitexact(o.traverse(rays), r.traverse(rays), s.name)
+        segs = scenes.shadow_segments(s, 3000, 6)
+        assert (o.visible(segs) == r.visible(segs)).all()
+        for i in (0, s.ntris // 3, s.ntris - 1):
+            assert (bits(o.tri_derived(i)) == bits(r.tri_derived(i))).all()
+        r.close()

@@ -1,0 +1,55 @@
+"""Shared helpers for the parity tests."""
+import glob
+import os
+
+import numpy as np
+
+from raytracer_amd import scenes
+from raytracer_amd.abi import HIT_DTYPE
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN_SCENES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not p.endswith("scalars.npz"))
+
+
+def load_golden(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    s = scenes.SceneData(name, g["verts"], g["tri_mat"], [scenes.Material()], [scenes.solid((0.7, 0.7, 0.7))])
+    s.tri_mat = np.zeros_like(g["tri_mat"])  # geometry-only fixtures: one material
+    hits = np.zeros(len(g["hit_t"]), HIT_DTYPE)
+    for k in ("ID", "t", "alpha", "beta", "gamma"):
+        hits[k] = g["hit_" + k.lower() if k != "ID" else "hit_id"]
+    return s, g, hits
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_hits_bitexact(got, want, what=""):
+    """hit/miss, triangle ID, t, alpha, beta, gamma identical bit for bit (no tolerance, no exclusions)."""
+    hg, hw = got["t"] < 3e38, want["t"] < 3e38
+    assert (hg == hw).all(), f"{what}: hit/miss differs on {int((hg != hw).sum())} rays"
+    assert (bits(got["t"]) == bits(want["t"])).all(), f"{what}: t bits differ on {int((bits(got['t']) != bits(want['t'])).sum())} rays"
+    m = hw
+    assert (got["ID"][m] == want["ID"][m]).all(), f"{what}: triangle ID differs on {int((got['ID'][m] != want['ID'][m]).sum())} rays"
+    for k in ("alpha", "beta", "gamma"):
+        assert (bits(got[k][m]) == bits(want[k][m])).all(), f"{what}: {k} bits differ"
+
+
+def rel_mse(img, ref, eps=1e-2):
+    """relative MSE as used for the north_star image gate: mean((a-b)^2 / (b^2 + eps))."""
+    img, ref = np.asarray(img, np.float64), np.asarray(ref, np.float64)
+    return float(np.mean((img - ref) ** 2 / (ref ** 2 + eps)))
+
+
+def axis_rays(s, n, seed=11):
+    rng = np.random.default_rng(seed)
+    v = s.verts[:, :, :3].reshape(-1, 3)
+    o = v[rng.integers(0, len(v), n)].astype(np.float32)
+    o[:, 1] += rng.choice([0.0, 0.5, 2.0], n).astype(np.float32)
+    d = np.zeros((n, 3), np.float32)
+    ax = rng.integers(0, 3, n)
+    d[np.arange(n), ax] = rng.choice([-1.0, 1.0], n)
+    two = rng.uniform(0, 1, n) < 0.4
+    d[two, (ax[two] + 1) % 3] = rng.uniform(-1, 1, two.sum()).astype(np.float32)
+    return np.concatenate([o, d], 1).astype(np.float32)
