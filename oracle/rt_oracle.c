@@ -973,6 +973,7 @@ static Col compute_direct(Ctx* c, const Shading* sd, Rng* rng) {
     const orc_scene* s = c->s;
     const orc_material* m = &s->mats[sd->mat];
     if (mat_is_specular(m)) return col(0, 0, 0);
+    if (s->nlights == 0) return col(0, 0, 0); /* upstream indexes lights[-1] (Scene.h:147): defined here as "no direct light" */
     float pmf, pdf; Col emitted;
     const LightRef* light = sample_light(s, rng, &pmf);
     V3 p = light_sample(s, light, rng, &emitted, &pdf);

@@ -1,0 +1,1003 @@
+// render.hip — RayTracer (Renderer.h:29) as a software wavefront path tracer for gfx950.
+//
+// One rt_render() call enqueues, per batch of B samples per pixel, a fixed sequence of persistent kernels
+//   generate -> { ctl -> extend -> shade -> connect [-> gather] } x 6 -> accumulate
+// on one HIP stream with no host round trip: queue lengths live in a device control block that each kernel
+// reads, waves pull 64-item chunks from work counters, live paths are compacted with ballot + prefix
+// appends (one atomic per wave per queue), and hits are binned per BSDF class so a shade wave runs one
+// material's code.  Path state is SoA float4 in HBM (80 B/path), the film is a plain fp32 RGB sum.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "rt_shading.h"
+#include "scene_dev.h"
+
+#define RT_NCLASS 6
+#define RT_FLAG_CANHIT 0x100u
+#define RT_FLAG_DEAD 0x200u
+
+struct Ctl {
+    uint32_t n_active[2];
+    uint32_t n_class[8];
+    uint32_t n_shadow;
+    uint32_t n_gather;
+    unsigned long long work[4];  // extend, shade, connect, gather
+    unsigned long long tot_closest, tot_any;
+};
+
+struct RBuf {  // device buffers of one renderer
+    float4 *ray_o, *ray_d, *hit, *thr, *rad;
+    uint32_t* q_active[2];
+    uint32_t* q_class;   // RT_NCLASS * cap
+    float4* shadow;      // 3 * cap
+    float4* gather;      // 4 * cap (radiosity requests)
+    float4* vpl;         // 4 * vpl_cap
+    uint32_t cap, vpl_slots;
+    uint32_t np_pad, tiles_x, w, h;
+};
+
+__device__ __forceinline__ unsigned long long fetch_chunk(unsigned long long* work) {
+    unsigned long long base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(work, 64ULL);
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
+    unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+// ballot + prefix-sum append: one atomic per wave, slots handed out in lane order
+__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0) return 0;
+    uint32_t lane = threadIdx.x & 63;
+    uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    return base + (uint32_t)__popcll(mask & ((1ULL << lane) - 1ULL));
+}
+__device__ __forceinline__ bool slot_pixel(const RBuf& R, uint32_t q, uint32_t& x, uint32_t& y) {
+    uint32_t tile = q >> 6, in = q & 63;
+    x = (tile % R.tiles_x) * 8 + (in & 7);
+    y = (tile / R.tiles_x) * 8 + (in >> 3);
+    return x < R.w && y < R.h;
+}
+__device__ __forceinline__ int class_of(uint32_t type) {
+    switch (type) {
+    case RT_MAT_MIRROR: return 1;
+    case RT_MAT_GLASS: return 2;
+    case RT_MAT_CONDUCTOR: return 3;
+    case RT_MAT_DIELECTRIC: return 4;
+    case RT_MAT_PLASTIC: return 5;
+    default: return 0;  // diffuse, oren-nayar
+    }
+}
+__device__ __forceinline__ f3 mul_point(const float* m, f3 v) {  // Core.h:302
+    return mk3((v.x * m[0] + v.y * m[1] + v.z * m[2]) + m[3], (v.x * m[4] + v.y * m[5] + v.z * m[6]) + m[7],
+               (v.x * m[8] + v.y * m[9] + v.z * m[10]) + m[11]);
+}
+__device__ __forceinline__ f3 mul_point_div(const float* m, f3 v) {  // Core.h:310
+    f3 a = mul_point(m, v);
+    float w = (m[12] * v.x) + (m[13] * v.y) + (m[14] * v.z) + m[15];
+    w = 1.0f / w;
+    return a * w;
+}
+__device__ __forceinline__ void camera_ray(const DCamera& c, float x, float y, f3& o, f3& dir) {  // Scene.h:47
+    float xc = ((2 * x) / (c.width - 1)) - 1;
+    float yc = 1 - ((2 * y) / (c.height - 1));
+    f3 pcam = mul_point_div(c.invP, mk3(xc, yc, 0));
+    f3 dcam = mul_point_div(c.cam, pcam);
+    o = ld3(c.origin);
+    dir = dcam - o;
+}
+__device__ __forceinline__ bool camera_project(const DCamera& c, f3 p, float& x, float& y) {  // Scene.h:65
+    f3 pview = mul_point(c.cam2view, p);
+    f3 pproj = mul_point_div(c.P, pview);
+    x = (pproj.x + 1.0f) * 0.5f;
+    y = (pproj.y + 1.0f) * 0.5f;
+    if (x < 0 || x > 1.0f || y < 0 || y > 1.0f) return false;
+    x = x * c.width;
+    y = 1.0f - y;
+    y = y * c.height;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ control
+__global__ void k_ctl_reset(Ctl* ctl, int cur, int first, uint32_t first_count) {
+    ctl->tot_any += ctl->n_shadow;
+    if (first) ctl->n_active[cur] = first_count;
+    ctl->tot_closest += ctl->n_active[cur];
+    ctl->n_active[cur ^ 1] = 0;
+    for (int i = 0; i < 8; i++) ctl->n_class[i] = 0;
+    ctl->n_shadow = 0;
+    ctl->n_gather = 0;
+    for (int i = 0; i < 4; i++) ctl->work[i] = 0;
+}
+__global__ void k_ctl_final(Ctl* ctl) {
+    ctl->tot_any += ctl->n_shadow;
+    ctl->n_shadow = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ generate
+// pathTrace(px, py, sampler) (Renderer.h:203): jitter in [0,1) added to px = x + 0.5 (Renderer.h:527, :205)
+__global__ __launch_bounds__(256) void k_generate(DScene S, RBuf R, uint32_t n, uint64_t seed, uint64_t first_sample) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint32_t s = i / R.np_pad, q = i - s * R.np_pad;
+        uint32_t x, y;
+        if (!slot_pixel(R, q, x, y)) { R.thr[i] = make_float4(0, 0, 0, __uint_as_float(RT_FLAG_DEAD)); continue; }
+        Rng rng; rng.key = rt_rng_key(seed, first_sample + s, y * R.w + x, 0); rng.ctr = 0;
+        float px = x + 0.5f, py = y + 0.5f;
+        float u1 = rt_rng_next(rng), u2 = rt_rng_next(rng);
+        f3 o, d;
+        camera_ray(S.cam, px + u1, py + u2, o, d);
+        R.ray_o[i] = make_float4(o.x, o.y, o.z, __uint_as_float(rng.key));
+        R.ray_d[i] = make_float4(d.x, d.y, d.z, __uint_as_float(rng.ctr));
+        R.thr[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(RT_FLAG_CANHIT));
+        R.rad[i] = make_float4(0, 0, 0, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ extend
+// Scene::traverse for every live path + the two trivial outcomes of pathTrace handled in place:
+// escaped rays add background->evaluate(dir) un-weighted (Renderer.h:254) and emitters add T*Le only when
+// canHitLight (Renderer.h:221-231).  Everything else is binned by BSDF class for the shade kernel.
+template <bool LT, bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene S, RBuf R, Ctl* ctl, int cur, int first, uint32_t* spill4, uint32_t* spill2,
+                                                     DCounters* counters) {
+    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
+    TravStack st; st.lds = lds_stack + threadIdx.x; st.glob = spill4 ? spill4 + gtid : nullptr; st.gstride = gstride;
+    const uint32_t n = ctl->n_active[cur];
+    const uint32_t* queue = R.q_active[cur];
+    uint32_t cn = 0, ct = 0, cx = 0;
+    for (;;) {
+        unsigned long long base = fetch_chunk(&ctl->work[0]);
+        if (base >= n) break;
+        uint32_t i = (uint32_t)base + (threadIdx.x & 63);
+        int cls = -1;
+        uint32_t path = 0;
+        if (i < n) {
+            path = first ? i : queue[i];
+            float4 th = R.thr[path];
+            uint32_t flags = __float_as_uint(th.w);
+            if (!(flags & RT_FLAG_DEAD)) {
+                float4 ro = R.ray_o[path], rd = R.ray_d[path];
+                f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
+                HitRec h;
+                rt_closest<COUNT>(S, o, d, 0, h, st, spill2 + gtid, gstride, cn, ct, cx);
+                if (h.t < RT_FLT_MAX) {
+                    uint32_t mat = S.tris[h.rank].mat_gsign & 0x7FFFFFFFu;
+                    const DMaterial& m = S.mats[mat];
+                    if (!LT && (m.flags & RT_MF_LIGHT)) {
+                        if (flags & RT_FLAG_CANHIT) {
+                            float4 L = R.rad[path];
+                            col3 c = mkc(th.x, th.y, th.z) * mat_emission(m);
+                            R.rad[path] = make_float4(L.x + c.r, L.y + c.g, L.z + c.b, L.w);
+                        }
+                    } else {
+                        R.hit[path] = make_float4(h.t, h.u, h.v, __uint_as_float(h.rank));
+                        cls = LT ? 0 : class_of(m.type);
+                    }
+                } else if (!LT) {
+                    float4 L = R.rad[path];
+                    col3 c = bg_evaluate(S, d);
+                    R.rad[path] = make_float4(L.x + c.r, L.y + c.g, L.z + c.b, L.w);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < (LT ? 1 : RT_NCLASS); c++) {
+            bool mine = cls == c;
+            uint32_t slot = wave_append(&ctl->n_class[c], mine);
+            if (mine) R.q_class[(size_t)c * R.cap + slot] = path;
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&counters->nodes, (unsigned long long)cn); atomicAdd(&counters->tris, (unsigned long long)ct);
+        atomicAdd(&counters->exact, (unsigned long long)cx);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ shade
+// Body of pathTrace after the hit (Renderer.h:232-252): NEE request (computeDirect, Renderer.h:155), depth
+// test, Russian roulette, BSDF sample, throughput update, next ray.  RADIOSITY adds the VPL gather request of
+// pathTraceRadiosity (Renderer.h:931).
+template <bool RADIOSITY>
+__global__ __launch_bounds__(256) void k_shade(DScene S, RBuf R, Ctl* ctl, int cur, int direct_only) {
+    uint32_t cnt[RT_NCLASS], total = 0;
+#pragma unroll
+    for (int c = 0; c < RT_NCLASS; c++) { cnt[c] = ctl->n_class[c]; total += cnt[c]; }
+    for (;;) {
+        unsigned long long base = fetch_chunk(&ctl->work[1]);
+        if (base >= total) break;
+        uint32_t g = (uint32_t)base + (threadIdx.x & 63);
+        bool live = g < total;
+        bool want_next = false, want_shadow = false, want_gather = false;
+        uint32_t path = 0;
+        float4 sh_a, sh_b, sh_c, ga, gb, gc, gd;
+        if (live) {
+            int c = 0; uint32_t idx = g;
+#pragma unroll
+            for (int k = 0; k < RT_NCLASS - 1; k++) if (c == k && idx >= cnt[k]) { idx -= cnt[k]; c = k + 1; }
+            path = R.q_class[(size_t)c * R.cap + idx];
+            float4 ro = R.ray_o[path], rd = R.ray_d[path], hh = R.hit[path], th = R.thr[path];
+            f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
+            Rng rng; rng.key = __float_as_uint(ro.w); rng.ctr = __float_as_uint(rd.w);
+            uint32_t flags = __float_as_uint(th.w);
+            uint32_t depth = flags & 0xFFu;
+            col3 T = mkc(th.x, th.y, th.z);
+            Shading sd = shading_data(S, o, d, hh.x, hh.y, hh.z, __float_as_uint(hh.w));
+            const DMaterial& m = S.mats[sd.mat];
+            const bool specular = (m.flags & RT_MF_SPECULAR) != 0;
+            // --- computeDirect
+            if (!specular && S.n_lights > 0) {
+                float pmf = 1.f / S.n_lights;
+                int li = (int)(S.n_lights * rt_rng_next(rng));
+                li = li < (int)S.n_lights - 1 ? li : (int)S.n_lights - 1;
+                DLight light = S.lights[li];
+                float r1 = rt_rng_next(rng), r2 = rt_rng_next(rng);
+                if (light.kind == 0) {
+                    const DTri& lt = S.tris[light.tri];
+                    col3 emitted = mat_emission(S.mats[lt.mat_gsign & 0x7FFFFFFFu]);
+                    f3 p = tri_sample_point(lt, r1, r2);
+                    float pdf = 1 / S.trishade[light.tri].area;
+                    f3 wi = p - sd.x;
+                    float l = lensq3(wi);
+                    wi = norm3(wi);
+                    float G = (smaxf_w(dot3(wi, sd.sN), 0.0f) * smaxf_w(-dot3(wi, tri_gnormal(lt)), 0.0f)) / l;
+                    if (G > 0) {
+                        col3 cd = ((bsdf_eval(S, sd, wi) * emitted) * G) / (pmf * pdf);
+                        col3 cc = T * cd;
+                        want_shadow = true;
+                        sh_a = make_float4(sd.x.x, sd.x.y, sd.x.z, __uint_as_float(path));
+                        sh_b = make_float4(p.x, p.y, p.z, 0);
+                        sh_c = make_float4(cc.r, cc.g, cc.b, 0);
+                    }
+                } else if (light.kind == 1) {
+                    f3 wi = uniform_sample_sphere(r1, r2);
+                    float pdf = uniform_sphere_pdf();
+                    col3 emitted = mkc(S.bg_colour[0], S.bg_colour[1], S.bg_colour[2]);
+                    float G = smaxf_w(dot3(wi, sd.sN), 0.0f);
+                    if (G > 0) {
+                        col3 cd = ((bsdf_eval(S, sd, wi) * emitted) * G) / (pmf * pdf);
+                        col3 cc = T * cd;
+                        f3 p2 = sd.x + (wi * 10000.0f);
+                        want_shadow = true;
+                        sh_a = make_float4(sd.x.x, sd.x.y, sd.x.z, __uint_as_float(path));
+                        sh_b = make_float4(p2.x, p2.y, p2.z, 0);
+                        sh_c = make_float4(cc.r, cc.g, cc.b, 0);
+                    }
+                }
+                // kind 2 (EnvironmentMap::sample): Vec2::operator[] truncates to int upstream (Sampling.h:204), so
+                // wi = (0,1,0) with pdf = inf and the term is 0; the two draws above are still consumed.
+            }
+            if (RADIOSITY && !specular) {
+                want_gather = true;
+                ga = make_float4(sd.x.x, sd.x.y, sd.x.z, __uint_as_float(path));
+                gb = make_float4(sd.sN.x, sd.sN.y, sd.sN.z, sd.tu);
+                gc = make_float4(sd.wo.x, sd.wo.y, sd.wo.z, sd.tv);
+                gd = make_float4(T.r, T.g, T.b, __uint_as_float(sd.mat));
+            }
+            if (!direct_only && !(depth > RT_MAX_DEPTH)) {
+                float lum = lumc(T);
+                float rr = lum < 0.9f ? lum : 0.9f;  // min(pathThroughput.Lum(), 0.9f) (Renderer.h:237)
+                if (rt_rng_next(rng) < rr) {
+                    T = T / rr;
+                    col3 f; float pdf;
+                    f3 wi = bsdf_sample(S, sd, rng, f, pdf);
+                    T = ((T * f) * fabsf(dot3(wi, sd.sN))) / pdf;
+                    f3 no = sd.x + (wi * RT_EPSILON);
+                    R.ray_o[path] = make_float4(no.x, no.y, no.z, ro.w);
+                    R.ray_d[path] = make_float4(wi.x, wi.y, wi.z, __uint_as_float(rng.ctr));
+                    R.thr[path] = make_float4(T.r, T.g, T.b, __uint_as_float((depth + 1) | (specular ? RT_FLAG_CANHIT : 0u)));
+                    want_next = true;
+                }
+            }
+        }
+        uint32_t s1 = wave_append(&ctl->n_shadow, want_shadow);
+        if (want_shadow) { float4* e = R.shadow + (size_t)s1 * 3; e[0] = sh_a; e[1] = sh_b; e[2] = sh_c; }
+        if (RADIOSITY) {
+            uint32_t s2 = wave_append(&ctl->n_gather, want_gather);
+            if (want_gather) { float4* e = R.gather + (size_t)s2 * 4; e[0] = ga; e[1] = gb; e[2] = gc; e[3] = gd; }
+        }
+        uint32_t s3 = wave_append(&ctl->n_active[cur ^ 1], want_next);
+        if (want_next) R.q_active[cur ^ 1][s3] = path;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ connect
+// Scene::visible for every NEE request; visible ones add their (already throughput-weighted) term.
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_connect(DScene S, RBuf R, Ctl* ctl, uint32_t* spill4, uint32_t* spill2, DCounters* counters) {
+    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
+    TravStack st; st.lds = lds_stack + threadIdx.x; st.glob = spill4 ? spill4 + gtid : nullptr; st.gstride = gstride;
+    const uint32_t n = ctl->n_shadow;
+    uint32_t cn = 0, ct = 0, cx = 0;
+    for (;;) {
+        unsigned long long base = fetch_chunk(&ctl->work[2]);
+        if (base >= n) break;
+        uint32_t i = (uint32_t)base + (threadIdx.x & 63);
+        if (i < n) {
+            const float4* e = R.shadow + (size_t)i * 3;
+            float4 a = e[0], b = e[1];
+            if (rt_visible<COUNT>(S, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), 0, st, spill2 + gtid, gstride, cn, ct, cx)) {
+                float4 c = e[2];
+                uint32_t path = __float_as_uint(a.w);
+                float4 L = R.rad[path];
+                R.rad[path] = make_float4(L.x + c.x, L.y + c.y, L.z + c.z, L.w);
+            }
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&counters->nodes, (unsigned long long)cn); atomicAdd(&counters->tris, (unsigned long long)ct);
+        atomicAdd(&counters->exact, (unsigned long long)cx);
+    }
+}
+
+// connectToCamera (Renderer.h:669-692): projection, visibility to the lens, We = 1/(Afilm cos^4), atomic splat
+__global__ __launch_bounds__(RT_BLOCK) void k_connect_camera(DScene S, RBuf R, Ctl* ctl, float* film, uint32_t* spill4, uint32_t* spill2) {
+    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
+    TravStack st; st.lds = lds_stack + threadIdx.x; st.glob = spill4 ? spill4 + gtid : nullptr; st.gstride = gstride;
+    const uint32_t n = ctl->n_shadow;
+    uint32_t cn = 0, ct = 0, cx = 0;
+    const DCamera& cam = S.cam;
+    for (;;) {
+        unsigned long long base = fetch_chunk(&ctl->work[2]);
+        if (base >= n) break;
+        uint32_t i = (uint32_t)base + (threadIdx.x & 63);
+        if (i < n) {
+            const float4* e = R.shadow + (size_t)i * 3;
+            float4 a = e[0];
+            f3 p = mk3(a.x, a.y, a.z);
+            float x, y;
+            if (!camera_project(cam, p, x, y)) continue;
+            f3 org = ld3(cam.origin);
+            if (!rt_visible<false>(S, p, org, 0, st, spill2 + gtid, gstride, cn, ct, cx)) continue;
+            f3 cd = norm3(p - org);
+            float costheta = dot3(ld3(cam.view_dir), cd);
+            if (costheta <= 0) continue;
+            float we = (float)(1.f / (cam.Afilm * pow((double)costheta, 4.0)));
+            float4 c = e[2];
+            int px = (int)x, py = (int)y;  // Film::splat with BoxFilter (Imaging.h:224)
+            if (px >= 0 && px < cam.iw && py >= 0 && py < cam.ih) {
+                float* f = film + ((size_t)py * cam.iw + px) * 3;
+                atomicAdd(f + 0, c.x * we); atomicAdd(f + 1, c.y * we); atomicAdd(f + 2, c.z * we);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ accumulate
+// film->splat(px, py, col) with the size-0 box filter: film[(int)py * W + (int)px] += col (Imaging.h:224, Renderer.h:535)
+__global__ __launch_bounds__(256) void k_accumulate(RBuf R, float* film, uint32_t batch) {
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < R.np_pad; q += gridDim.x * blockDim.x) {
+        uint32_t x, y;
+        if (!slot_pixel(R, q, x, y)) continue;
+        float* f = film + ((size_t)y * R.w + x) * 3;
+        float r = f[0], g = f[1], b = f[2];
+        for (uint32_t s = 0; s < batch; s++) {
+            float4 L = R.rad[(size_t)s * R.np_pad + q];
+            r = r + L.x; g = g + L.y; b = b + L.z;
+        }
+        f[0] = r; f[1] = g; f[2] = b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ AOV / direct
+// albedo(), viewNormals(), direct() (Renderer.h:257-296): one ray through the pixel centre (Renderer.h:590).
+__global__ __launch_bounds__(RT_BLOCK) void k_aov(DScene S, RBuf R, Ctl* ctl, int mode, uint64_t seed, uint64_t first_sample, uint32_t n,
+                                                  uint32_t* spill4, uint32_t* spill2) {
+    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
+    TravStack st; st.lds = lds_stack + threadIdx.x; st.glob = spill4 ? spill4 + gtid : nullptr; st.gstride = gstride;
+    uint32_t cn = 0, ct = 0, cx = 0;
+    for (;;) {
+        unsigned long long base = fetch_chunk(&ctl->work[0]);
+        if (base >= n) break;
+        uint32_t i = (uint32_t)base + (threadIdx.x & 63);
+        bool want_shadow = false;
+        float4 sh_a, sh_b, sh_c;
+        if (i < n) {
+            uint32_t s = i / R.np_pad, q = i - s * R.np_pad, x, y;
+            col3 out = mkc(0, 0, 0);
+            if (slot_pixel(R, q, x, y)) {
+                Rng rng; rng.key = rt_rng_key(seed, first_sample + s, y * R.w + x, 0); rng.ctr = 0;
+                f3 o, d;
+                camera_ray(S.cam, x + 0.5f, y + 0.5f, o, d);
+                HitRec h;
+                rt_closest<false>(S, o, d, 0, h, st, spill2 + gtid, gstride, cn, ct, cx);
+                if (h.t < RT_FLT_MAX) {
+                    Shading sd = shading_data(S, o, d, h.t, h.u, h.v, h.rank);
+                    const DMaterial& m = S.mats[sd.mat];
+                    if (mode == RT_MODE_AOV_NORMAL) out = mkc(fabsf(sd.sN.x), fabsf(sd.sN.y), fabsf(sd.sN.z));
+                    else if (m.flags & RT_MF_LIGHT) out = mat_emission(m);
+                    else if (mode == RT_MODE_AOV_ALBEDO) out = bsdf_eval(S, sd, mk3(0, 1, 0));
+                    else if (!(m.flags & RT_MF_SPECULAR) && S.n_lights > 0) {  // computeDirect
+                        float pmf = 1.f / S.n_lights;
+                        int li = (int)(S.n_lights * rt_rng_next(rng));
+                        li = li < (int)S.n_lights - 1 ? li : (int)S.n_lights - 1;
+                        DLight light = S.lights[li];
+                        float r1 = rt_rng_next(rng), r2 = rt_rng_next(rng);
+                        if (light.kind == 0) {
+                            const DTri& lt = S.tris[light.tri];
+                            col3 emitted = mat_emission(S.mats[lt.mat_gsign & 0x7FFFFFFFu]);
+                            f3 p = tri_sample_point(lt, r1, r2);
+                            float pdf = 1 / S.trishade[light.tri].area;
+                            f3 wi = p - sd.x;
+                            float l = lensq3(wi);
+                            wi = norm3(wi);
+                            float G = (smaxf_w(dot3(wi, sd.sN), 0.0f) * smaxf_w(-dot3(wi, tri_gnormal(lt)), 0.0f)) / l;
+                            if (G > 0) {
+                                col3 cd = ((bsdf_eval(S, sd, wi) * emitted) * G) / (pmf * pdf);
+                                want_shadow = true;
+                                sh_a = make_float4(sd.x.x, sd.x.y, sd.x.z, __uint_as_float(i));
+                                sh_b = make_float4(p.x, p.y, p.z, 0);
+                                sh_c = make_float4(cd.r, cd.g, cd.b, 0);
+                            }
+                        } else if (light.kind == 1) {
+                            f3 wi = uniform_sample_sphere(r1, r2);
+                            float G = smaxf_w(dot3(wi, sd.sN), 0.0f);
+                            if (G > 0) {
+                                col3 emitted = mkc(S.bg_colour[0], S.bg_colour[1], S.bg_colour[2]);
+                                col3 cd = ((bsdf_eval(S, sd, wi) * emitted) * G) / (pmf * uniform_sphere_pdf());
+                                f3 p2 = sd.x + (wi * 10000.0f);
+                                want_shadow = true;
+                                sh_a = make_float4(sd.x.x, sd.x.y, sd.x.z, __uint_as_float(i));
+                                sh_b = make_float4(p2.x, p2.y, p2.z, 0);
+                                sh_c = make_float4(cd.r, cd.g, cd.b, 0);
+                            }
+                        }
+                    }
+                } else if (mode == RT_MODE_AOV_ALBEDO) out = bg_evaluate(S, d);
+            }
+            R.rad[i] = make_float4(out.r, out.g, out.b, 0);
+        }
+        uint32_t s1 = wave_append(&ctl->n_shadow, want_shadow);
+        if (want_shadow) { float4* e = R.shadow + (size_t)s1 * 3; e[0] = sh_a; e[1] = sh_b; e[2] = sh_c; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ light tracing
+// lightTrace (Renderer.h:695-719): sample light, position, direction; Le = evaluate(-wi)/pdfPosition; connect the
+// light vertex to the camera; shoot the path from p (no epsilon offset, as upstream).
+__device__ inline void light_emit(const DScene& S, Rng& rng, float N_vpl, bool for_vpl, f3& p, f3& wi, col3& Le, f3& ln, bool& ok) {
+    ok = false;
+    if (S.n_lights == 0) return;
+    float pmf = 1.f / S.n_lights;
+    int li = (int)(S.n_lights * rt_rng_next(rng));
+    li = li < (int)S.n_lights - 1 ? li : (int)S.n_lights - 1;
+    DLight light = S.lights[li];
+    float pdfPos, pdfDir;
+    float r1 = rt_rng_next(rng), r2 = rt_rng_next(rng);
+    float r3 = rt_rng_next(rng), r4 = rt_rng_next(rng);
+    col3 emitted;
+    if (light.kind == 0) {
+        const DTri& lt = S.tris[light.tri];
+        p = tri_sample_point(lt, r1, r2);                              // samplePositionFromLight (Lights.h:66)
+        pdfPos = 1 / S.trishade[light.tri].area;
+        f3 wl = cosine_sample_hemisphere(r3, r4);                      // sampleDirectionFromLight (Lights.h:70)
+        pdfDir = cosine_hemisphere_pdf(wl);
+        ln = tri_gnormal(lt);
+        Frame3 fr = frame_from(ln);
+        wi = to_world(fr, wl);
+        emitted = mat_emission(S.mats[lt.mat_gsign & 0x7FFFFFFFu]);
+        if (!for_vpl) {
+            f3 mw = -wi;                                               // AreaLight::evaluate(-wi) (Lights.h:42)
+            Le = (dot3(mw, ln) < 0) ? emitted : mkc(0, 0, 0);
+            Le = Le / pdfPos;
+        }
+    } else {
+        p = uniform_sample_sphere(r1, r2);                             // Lights.h:122, :327
+        p = p * S.scene_radius;
+        p = p + ld3(S.scene_centre);
+        if (light.kind == 1) pdfPos = (float)(4 * RT_PI * S.scene_radius * S.scene_radius);  // sic
+        else pdfPos = (float)(1.0f / (4 * RT_PI * (S.scene_radius * S.scene_radius)));
+        if (light.kind == 1) { wi = uniform_sample_sphere(r3, r4); pdfDir = uniform_sphere_pdf(); }
+        else { wi = mk3(0, 1, 0); pdfDir = RT_INF; }                   // Vec2 truncation, see k_shade
+        emitted = light.kind == 1 ? mkc(S.bg_colour[0], S.bg_colour[1], S.bg_colour[2]) : bg_evaluate(S, mk3(0, 1, 0));
+        ln = -p;                                                       // normal(shadingData, p) = -p (Lights.h:114)
+        if (!for_vpl) Le = bg_evaluate(S, -wi) / pdfPos;
+    }
+    if (for_vpl) {  // traceVPLs (Renderer.h:788-797): light->sample() consumes two more draws, emitted = emission
+        (void)rt_rng_next(rng); (void)rt_rng_next(rng);
+        Le = (emitted * fabsf(dot3(wi, ln))) / (pmf * pdfPos * pdfDir * N_vpl);
+    }
+    ok = true;
+}
+
+__global__ __launch_bounds__(256) void k_lt_generate(DScene S, RBuf R, Ctl* ctl, uint32_t n, uint32_t npix, uint64_t seed, uint64_t first_sample) {
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+        uint32_t i = base + threadIdx.x;
+        bool ok = false;
+        f3 p, wi, ln; col3 Le;
+        if (i < n) {
+            uint32_t s = i / npix, pix = i - s * npix;
+            Rng rng; rng.key = rt_rng_key(seed, first_sample + s, pix, 1); rng.ctr = 0;
+            light_emit(S, rng, 0.0f, false, p, wi, Le, ln, ok);
+            if (ok) {
+                R.ray_o[i] = make_float4(p.x, p.y, p.z, __uint_as_float(rng.key));
+                R.ray_d[i] = make_float4(wi.x, wi.y, wi.z, __uint_as_float(rng.ctr));
+                R.thr[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(0u));
+                R.rad[i] = make_float4(Le.r, Le.g, Le.b, 0);
+            } else R.thr[i] = make_float4(0, 0, 0, __uint_as_float(RT_FLAG_DEAD));
+        }
+        uint32_t s1 = wave_append(&ctl->n_shadow, ok);
+        if (ok) { float4* e = R.shadow + (size_t)s1 * 3; e[0] = make_float4(p.x, p.y, p.z, 0); e[1] = make_float4(0, 0, 0, 0); e[2] = make_float4(Le.r, Le.g, Le.b, 0); }
+    }
+}
+
+// lightTracePath (Renderer.h:722-767)
+__global__ __launch_bounds__(256) void k_lt_shade(DScene S, RBuf R, Ctl* ctl, int cur) {
+    const uint32_t total = ctl->n_class[0];
+    for (;;) {
+        unsigned long long base = fetch_chunk(&ctl->work[1]);
+        if (base >= total) break;
+        uint32_t g = (uint32_t)base + (threadIdx.x & 63);
+        bool live = g < total, want_next = false;
+        uint32_t path = 0;
+        float4 sh_a, sh_c;
+        if (live) {
+            path = R.q_class[g];
+            float4 ro = R.ray_o[path], rd = R.ray_d[path], hh = R.hit[path], th = R.thr[path], le4 = R.rad[path];
+            f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
+            Rng rng; rng.key = __float_as_uint(ro.w); rng.ctr = __float_as_uint(rd.w);
+            uint32_t depth = __float_as_uint(th.w) & 0xFFu;
+            col3 T = mkc(th.x, th.y, th.z), Le = mkc(le4.x, le4.y, le4.z);
+            Shading sd = shading_data(S, o, d, hh.x, hh.y, hh.z, __float_as_uint(hh.w));
+            const DMaterial& m = S.mats[sd.mat];
+            f3 wc = norm3(ld3(S.cam.origin) - sd.x);
+            col3 c = (T * bsdf_eval(S, sd, wc)) * Le;
+            sh_a = make_float4(sd.x.x, sd.x.y, sd.x.z, 0);
+            sh_c = make_float4(c.r, c.g, c.b, 0);
+            if (!(m.flags & RT_MF_LIGHT) && !(depth > RT_MAX_DEPTH)) {
+                float lum = lumc(T);
+                float rr = lum < 0.9f ? lum : 0.9f;
+                if (rt_rng_next(rng) < rr) {
+                    T = T / rr;
+                    float r1 = rt_rng_next(rng), r2 = rt_rng_next(rng);
+                    f3 nw = cosine_sample_hemisphere(r1, r2);
+                    float pdf = cosine_hemisphere_pdf(wc);  // sic: world-space direction to the camera (Renderer.h:757)
+                    nw = to_world(sd.frame, nw);
+                    col3 f = bsdf_eval(S, sd, nw);
+                    T = ((T * f) * fabsf(dot3(nw, sd.sN))) / pdf;
+                    f3 no = sd.x + (nw * RT_EPSILON);
+                    R.ray_o[path] = make_float4(no.x, no.y, no.z, ro.w);
+                    R.ray_d[path] = make_float4(nw.x, nw.y, nw.z, __uint_as_float(rng.ctr));
+                    R.thr[path] = make_float4(T.r, T.g, T.b, __uint_as_float(depth + 1));
+                    want_next = true;
+                }
+            }
+        }
+        uint32_t s1 = wave_append(&ctl->n_shadow, live);
+        if (live) { float4* e = R.shadow + (size_t)s1 * 3; e[0] = sh_a; e[1] = make_float4(0, 0, 0, 0); e[2] = sh_c; }
+        uint32_t s3 = wave_append(&ctl->n_active[cur ^ 1], want_next);
+        if (want_next) R.q_active[cur ^ 1][s3] = path;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ instant radiosity
+// traceVPLs / VPLTracePath (Renderer.h:772-863): one lane per light sample, <= 6 records each, fixed slots so the
+// gather order is reproducible.  record: a=(x, mat|-1) b=(sN, tu) c=(wo, tv) d=(Le, valid)
+__global__ __launch_bounds__(64) void k_vpl_trace(DScene S, RBuf R, int n_vpl, uint64_t seed, uint32_t* spill2, Ctl* ctl) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t gstride = gridDim.x * blockDim.x;
+    if (i >= (uint32_t)n_vpl) return;
+    float4* rec = R.vpl + (size_t)i * 6 * 4;
+    for (int k = 0; k < 6; k++) rec[k * 4 + 3] = make_float4(0, 0, 0, 0);
+    Rng rng; rng.key = rt_rng_key(seed, 0, i, 3); rng.ctr = 0;
+    f3 p, wi, ln; col3 Le; bool ok;
+    light_emit(S, rng, (float)n_vpl, true, p, wi, Le, ln, ok);
+    if (!ok) return;
+    int slot = 0;
+    rec[0] = make_float4(p.x, p.y, p.z, __int_as_float(-1));
+    rec[1] = make_float4(ln.x, ln.y, ln.z, 0); rec[2] = make_float4(0, 0, 0, 0); rec[3] = make_float4(Le.r, Le.g, Le.b, 1.0f);
+    slot = 1;
+    f3 o = p + (wi * RT_EPSILON), d = wi;
+    col3 T = mkc(1, 1, 1);
+    uint32_t cn = 0, ct = 0, nrays = 0;
+    for (int depth = 0; depth <= RT_MAX_DEPTH; depth++) {
+        HitRec h; h.t = RT_FLT_MAX; h.u = h.v = 0; h.rank = 0xFFFFFFFFu;
+        nrays++;
+        if (S.root_ref != RT_REF_EMPTY) rt_walk_reference<false, false>(S, o, d, 0.0f, h, spill2 + i, gstride, cn, ct);
+        if (!(h.t < RT_FLT_MAX)) break;
+        Shading sd = shading_data(S, o, d, h.t, h.u, h.v, h.rank);
+        float lum = lumc(T);
+        float rr = lum < 0.9f ? lum : 0.9f;
+        if (rt_rng_next(rng) < rr) T = T / rr; else break;
+        col3 c = T * Le;
+        float4* e = rec + slot * 4;
+        e[0] = make_float4(sd.x.x, sd.x.y, sd.x.z, __int_as_float((int)sd.mat));
+        e[1] = make_float4(sd.sN.x, sd.sN.y, sd.sN.z, sd.tu);
+        e[2] = make_float4(sd.wo.x, sd.wo.y, sd.wo.z, sd.tv);
+        e[3] = make_float4(c.r, c.g, c.b, 1.0f);
+        slot++;
+        col3 f; float pdf;
+        f3 w2 = bsdf_sample(S, sd, rng, f, pdf);
+        T = ((T * f) * fabsf(dot3(w2, sd.sN))) / pdf;
+        o = sd.x + (w2 * RT_EPSILON); d = w2;
+    }
+    atomicAdd(&ctl->tot_closest, (unsigned long long)nrays);
+}
+
+// computeVPLContribution (Renderer.h:870-907): one lane per shading point, VPLs in slot order; cosine tests run
+// before the shadow ray (same sum, fewer rays than upstream which traces first).
+__global__ __launch_bounds__(RT_BLOCK) void k_gather(DScene S, RBuf R, Ctl* ctl, uint32_t* spill4, uint32_t* spill2) {
+    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
+    TravStack st; st.lds = lds_stack + threadIdx.x; st.glob = spill4 ? spill4 + gtid : nullptr; st.gstride = gstride;
+    const uint32_t n = ctl->n_gather;
+    uint32_t cn = 0, ct = 0, cx = 0;
+    unsigned long long nrays = 0;
+    for (;;) {
+        unsigned long long base = fetch_chunk(&ctl->work[3]);
+        if (base >= n) break;
+        uint32_t i = (uint32_t)base + (threadIdx.x & 63);
+        if (i < n) {
+            const float4* e = R.gather + (size_t)i * 4;
+            float4 a = e[0], b = e[1], c = e[2], dd = e[3];
+            Shading sd;
+            sd.x = mk3(a.x, a.y, a.z); sd.sN = mk3(b.x, b.y, b.z); sd.gN = sd.sN; sd.wo = mk3(c.x, c.y, c.z);
+            sd.tu = b.w; sd.tv = c.w; sd.mat = __float_as_uint(dd.w);
+            sd.frame = frame_from(sd.sN);
+            col3 sum = mkc(0, 0, 0);
+            for (uint32_t v = 0; v < R.vpl_slots; v++) {
+                const float4* r = R.vpl + (size_t)v * 4;
+                float4 r3 = r[3];
+                if (r3.w == 0.0f) continue;
+                float4 r0 = r[0], r1 = r[1];
+                f3 vx = mk3(r0.x, r0.y, r0.z), vn = mk3(r1.x, r1.y, r1.z);
+                f3 wi = vx - sd.x;
+                float dist = len3(wi);
+                wi = norm3(wi);
+                float cx_ = dot3(sd.sN, wi), cxi = dot3(vn, -wi);
+                if (cx_ <= 0.0f || cxi <= 0.0f) continue;
+                float G = cx_ * cxi / (dist * dist);
+                if (G <= 0.0f) continue;
+                nrays++;
+                if (!rt_visible<false>(S, sd.x, vx, 0, st, spill2 + gtid, gstride, cn, ct, cx)) continue;
+                col3 fx = bsdf_eval(S, sd, wi);
+                col3 Le = mkc(r3.x, r3.y, r3.z);
+                int vmat = __float_as_int(r0.w);
+                if (vmat < 0 || (S.mats[vmat].flags & RT_MF_LIGHT)) sum = sum + ((fx * G) * Le);
+                else {
+                    float4 r2 = r[2];
+                    Shading vs;
+                    vs.x = vx; vs.sN = vn; vs.gN = vn; vs.wo = mk3(r2.x, r2.y, r2.z); vs.tu = r1.w; vs.tv = r2.w; vs.mat = (uint32_t)vmat;
+                    vs.frame = frame_from(vn);
+                    col3 fxi = bsdf_eval(S, vs, -wi);
+                    sum = sum + (((fx * G) * fxi) * Le);
+                }
+            }
+            uint32_t path = __float_as_uint(a.w);
+            col3 add = mkc(dd.x, dd.y, dd.z) * sum;
+            float4 L = R.rad[path];
+            R.rad[path] = make_float4(L.x + add.r, L.y + add.g, L.z + add.b, L.w);
+        }
+    }
+    if (nrays) atomicAdd(&ctl->tot_any, nrays);
+}
+
+// ------------------------------------------------------------------------------------------------ debug probes
+__global__ void k_debug_bsdf(DScene S, uint32_t mat, const float* wo, const float* n, const float* uv, const uint32_t* kc, const float* wi,
+                             size_t count, float* out, int do_sample) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Shading sd;
+    sd.x = mk3(0, 0, 0); sd.wo = ld3(wo + i * 3); sd.sN = ld3(n + i * 3); sd.gN = sd.sN;
+    sd.tu = uv[i * 2]; sd.tv = uv[i * 2 + 1]; sd.mat = mat;
+    if ((S.mats[mat].flags & RT_MF_TWOSIDED) && dot3(sd.wo, sd.sN) < 0) { sd.sN = -sd.sN; sd.gN = sd.sN; }
+    sd.frame = frame_from(sd.sN);
+    if (do_sample) {
+        Rng rng; rng.key = kc[i * 2]; rng.ctr = kc[i * 2 + 1];
+        col3 f; float pdf;
+        f3 w = bsdf_sample(S, sd, rng, f, pdf);
+        float* o = out + i * 7;
+        o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = f.r; o[4] = f.g; o[5] = f.b; o[6] = pdf;
+    } else {
+        f3 w = ld3(wi + i * 3);
+        col3 f = bsdf_eval(S, sd, w);
+        float* o = out + i * 4;
+        o[0] = f.r; o[1] = f.g; o[2] = f.b; o[3] = bsdf_pdf(S, sd, w);
+    }
+}
+
+// ================================================================================================= host side
+struct rt_renderer {
+    rt_scene* scene = nullptr;
+    int W = 0, H = 0;
+    hipStream_t stream = nullptr;
+    RBuf R{};
+    Ctl* ctl = nullptr;
+    DCounters* counters = nullptr;
+    float* film_own = nullptr;
+    float* film = nullptr;
+    int spp = 0;
+    uint32_t batch_max = 1;
+    uint32_t* spill4 = nullptr;
+    uint32_t* spill2 = nullptr;
+    int trav_blocks = 0, flat_blocks = 0;
+    int n_vpl = 0;
+    bool count_enabled = false;
+    std::vector<void*> allocs;
+};
+
+template <class T>
+static int dev_alloc(rt_renderer* r, T** p, size_t count) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, sizeof(T) * std::max<size_t>(count, 1));
+    if (e != hipSuccess) { rt_set_error(std::string("rt_renderer_create: hipMalloc: ") + hipGetErrorString(e)); return RT_ERR_NOMEM; }
+    r->allocs.push_back(q);
+    *p = (T*)q;
+    return RT_OK;
+}
+
+extern "C" void rt_renderer_destroy(rt_renderer* r) {
+    if (!r) return;
+    if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
+    for (void* p : r->allocs) (void)hipFree(p);
+    delete r;
+}
+
+extern "C" int rt_renderer_create(rt_scene* scene, rt_renderer** out) {
+    if (!scene || !out) { rt_set_error("rt_renderer_create: NULL argument"); return RT_ERR_INVALID; }
+    if (!scene->has_camera) { rt_set_error("rt_renderer_create: scene has no camera (rt_scene_set_camera)"); return RT_ERR_INVALID; }
+    *out = nullptr;
+    rt_renderer* r = new rt_renderer();
+    r->scene = scene;
+    r->W = scene->d.cam.iw; r->H = scene->d.cam.ih;
+    RBuf& R = r->R;
+    R.w = (uint32_t)r->W; R.h = (uint32_t)r->H;
+    R.tiles_x = (R.w + 7) / 8;
+    uint32_t tiles_y = (R.h + 7) / 8;
+    R.np_pad = R.tiles_x * tiles_y * 64;
+    // batch: as many samples per pixel as fit ~16 M paths (about 3 GB of wavefront state; the card has 288 GB)
+    r->batch_max = std::max<uint32_t>(1, std::min<uint32_t>(64, (16u << 20) / R.np_pad));
+    R.cap = R.np_pad * r->batch_max;
+    auto fail = [&](int rc) { rt_renderer_destroy(r); return rc; };
+    int rc;
+    if (hipStreamCreate(&r->stream) != hipSuccess) { rt_set_error("rt_renderer_create: hipStreamCreate failed"); return fail(RT_ERR_DEVICE); }
+    if ((rc = dev_alloc(r, &R.ray_o, R.cap)) || (rc = dev_alloc(r, &R.ray_d, R.cap)) || (rc = dev_alloc(r, &R.hit, R.cap)) ||
+        (rc = dev_alloc(r, &R.thr, R.cap)) || (rc = dev_alloc(r, &R.rad, R.cap)) || (rc = dev_alloc(r, &R.q_active[0], R.cap)) ||
+        (rc = dev_alloc(r, &R.q_active[1], R.cap)) || (rc = dev_alloc(r, &R.q_class, (size_t)R.cap * RT_NCLASS)) ||
+        (rc = dev_alloc(r, &R.shadow, (size_t)R.cap * 3)) || (rc = dev_alloc(r, &r->ctl, 1)) || (rc = dev_alloc(r, &r->counters, 1)) ||
+        (rc = dev_alloc(r, &r->film_own, (size_t)r->W * r->H * 3)))
+        return fail(rc);
+    R.gather = nullptr; R.vpl = nullptr; R.vpl_slots = 0;
+    r->film = r->film_own;
+    r->trav_blocks = scene->persistent_blocks;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, scene->device) != hipSuccess) return fail(RT_ERR_DEVICE);
+    r->flat_blocks = prop.multiProcessorCount * 8;
+    size_t threads = (size_t)r->trav_blocks * RT_BLOCK;
+    if (scene->host.max_stack4 > RT_STACK_LDS && (rc = dev_alloc(r, &r->spill4, threads * (scene->host.max_stack4 - RT_STACK_LDS)))) return fail(rc);
+    if ((rc = dev_alloc(r, &r->spill2, threads * std::max<uint32_t>(scene->host.max_stack2, 2)))) return fail(rc);
+    if (hipMemsetAsync(r->ctl, 0, sizeof(Ctl), r->stream) != hipSuccess || hipMemsetAsync(r->counters, 0, sizeof(DCounters), r->stream) != hipSuccess ||
+        hipMemsetAsync(r->film_own, 0, sizeof(float) * (size_t)r->W * r->H * 3, r->stream) != hipSuccess)
+        return fail(RT_ERR_DEVICE);
+    *out = r;
+    return RT_OK;
+}
+
+#define LAUNCH(kernel, blocks, threads, ...) hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), 0, r->stream, __VA_ARGS__)
+
+static int render_path_like(rt_renderer* r, int mode, uint32_t batch, uint64_t seed, uint64_t first_sample) {
+    const DScene& S = r->scene->d;
+    RBuf& R = r->R;
+    const bool radiosity = mode == RT_MODE_RADIOSITY && r->n_vpl > 0;
+    const uint32_t n = R.np_pad * batch;
+    LAUNCH(k_generate, r->flat_blocks, 256, S, R, n, seed, first_sample);
+    const int bounces = (mode == RT_MODE_DIRECT) ? 1 : RT_MAX_DEPTH + 2;
+    for (int b = 0; b < bounces; b++) {
+        int cur = b & 1;
+        LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n);
+        if (r->count_enabled) LAUNCH((k_extend<false, true>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
+        else LAUNCH((k_extend<false, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
+        if (radiosity) LAUNCH(k_shade<true>, r->flat_blocks, 256, S, R, r->ctl, cur, 0);
+        else LAUNCH(k_shade<false>, r->flat_blocks, 256, S, R, r->ctl, cur, mode == RT_MODE_DIRECT ? 1 : 0);
+        if (r->count_enabled) LAUNCH(k_connect<true>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
+        else LAUNCH(k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
+        if (radiosity) LAUNCH(k_gather, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2);
+    }
+    LAUNCH(k_ctl_final, 1, 1, r->ctl);
+    LAUNCH(k_accumulate, r->flat_blocks, 256, R, r->film, batch);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+static int render_aov(rt_renderer* r, int mode, uint32_t batch, uint64_t seed, uint64_t first_sample) {
+    const DScene& S = r->scene->d;
+    RBuf& R = r->R;
+    const uint32_t n = R.np_pad * batch;
+    LAUNCH(k_ctl_reset, 1, 1, r->ctl, 0, 1, n);
+    LAUNCH(k_aov, r->trav_blocks, RT_BLOCK, S, R, r->ctl, mode, seed, first_sample, n, r->spill4, r->spill2);
+    LAUNCH(k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
+    LAUNCH(k_ctl_final, 1, 1, r->ctl);
+    LAUNCH(k_accumulate, r->flat_blocks, 256, R, r->film, batch);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+static int render_light(rt_renderer* r, uint32_t batch, uint64_t seed, uint64_t first_sample) {
+    const DScene& S = r->scene->d;
+    RBuf& R = r->R;
+    const uint32_t npix = (uint32_t)r->W * r->H;
+    const uint32_t n = npix * batch;  // W*H light paths per spp (Renderer.h:331-337)
+    LAUNCH(k_ctl_reset, 1, 1, r->ctl, 0, 1, n);
+    LAUNCH(k_lt_generate, r->flat_blocks, 256, S, R, r->ctl, n, npix, seed, first_sample);
+    LAUNCH(k_connect_camera, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->spill4, r->spill2);
+    for (int b = 0; b < RT_MAX_DEPTH + 2; b++) {
+        int cur = b & 1;
+        LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n);
+        LAUNCH((k_extend<true, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
+        LAUNCH(k_lt_shade, r->flat_blocks, 256, S, R, r->ctl, cur);
+        LAUNCH(k_connect_camera, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->spill4, r->spill2);
+    }
+    LAUNCH(k_ctl_final, 1, 1, r->ctl);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+extern "C" int rt_render(rt_renderer* r, int mode, int spp, uint64_t seed, uint64_t first_sample) {
+    if (!r || spp < 0) { rt_set_error("rt_render: bad argument"); return RT_ERR_INVALID; }
+    if (mode == RT_MODE_PATH_ST) mode = RT_MODE_PATH;
+    if (mode == RT_MODE_MLT) { rt_set_error("rt_render: RT_MODE_MLT (PSSMLT) is not implemented in this round"); return RT_ERR_UNSUPPORTED; }
+    if (mode != RT_MODE_PATH && mode != RT_MODE_LIGHT && mode != RT_MODE_RADIOSITY && mode != RT_MODE_AOV_ALBEDO && mode != RT_MODE_AOV_NORMAL &&
+        mode != RT_MODE_DIRECT) { rt_set_error("rt_render: unknown mode"); return RT_ERR_INVALID; }
+    RT_HIP(hipSetDevice(r->scene->device));
+    r->count_enabled = r->scene->count_enabled;  // node/triangle fetch counting (atomics) follows rt_counters_enable
+    uint32_t bmax = r->batch_max;
+    if (mode == RT_MODE_LIGHT) bmax = std::max<uint32_t>(1, r->R.cap / ((uint32_t)r->W * r->H));
+    int done = 0;
+    while (done < spp) {
+        uint32_t b = std::min<uint32_t>(bmax, (uint32_t)(spp - done));
+        int rc;
+        if (mode == RT_MODE_LIGHT) rc = render_light(r, b, seed, first_sample + done);
+        else if (mode == RT_MODE_AOV_ALBEDO || mode == RT_MODE_AOV_NORMAL) rc = render_aov(r, mode, b, seed, first_sample + done);
+        else rc = render_path_like(r, mode, b, seed, first_sample + done);
+        if (rc) return rc;
+        done += (int)b;
+    }
+    r->spp += spp;  // film->incrementSPP() once per render() upstream (Renderer.h:399)
+    return RT_OK;
+}
+
+extern "C" int rt_renderer_sync(rt_renderer* r) {
+    if (!r) { rt_set_error("rt_renderer_sync: NULL"); return RT_ERR_INVALID; }
+    RT_HIP(hipStreamSynchronize(r->stream));
+    return RT_OK;
+}
+extern "C" int rt_film_clear(rt_renderer* r) {  // Film::clear (Imaging.h:269)
+    if (!r) { rt_set_error("rt_film_clear: NULL"); return RT_ERR_INVALID; }
+    RT_HIP(hipMemsetAsync(r->film, 0, sizeof(float) * (size_t)r->W * r->H * 3, r->stream));
+    r->spp = 0;
+    return RT_OK;
+}
+extern "C" int rt_film_spp(const rt_renderer* r) { return r ? r->spp : 0; }
+extern "C" int rt_film_set_spp(rt_renderer* r, int spp) {
+    if (!r || spp < 0) { rt_set_error("rt_film_set_spp: bad argument"); return RT_ERR_INVALID; }
+    r->spp = spp;
+    return RT_OK;
+}
+extern "C" int rt_film_read(rt_renderer* r, float* rgb, int* spp) {
+    if (!r || !rgb) { rt_set_error("rt_film_read: NULL argument"); return RT_ERR_INVALID; }
+    RT_HIP(hipStreamSynchronize(r->stream));
+    RT_HIP(hipMemcpy(rgb, r->film, sizeof(float) * (size_t)r->W * r->H * 3, hipMemcpyDeviceToHost));
+    if (spp) *spp = r->spp;
+    return RT_OK;
+}
+extern "C" int rt_film_bind(rt_renderer* r, float* d_film) {
+    if (!r) { rt_set_error("rt_film_bind: NULL"); return RT_ERR_INVALID; }
+    RT_HIP(hipStreamSynchronize(r->stream));
+    r->film = d_film ? d_film : r->film_own;
+    return RT_OK;
+}
+extern "C" int rt_render_counters(rt_renderer* r, rt_counters* o, int reset) {
+    if (!r || !o) { rt_set_error("rt_render_counters: NULL argument"); return RT_ERR_INVALID; }
+    RT_HIP(hipStreamSynchronize(r->stream));
+    Ctl c; DCounters d;
+    RT_HIP(hipMemcpy(&c, r->ctl, sizeof(c), hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(&d, r->counters, sizeof(d), hipMemcpyDeviceToHost));
+    o->closest_rays = c.tot_closest; o->any_rays = c.tot_any; o->nodes_visited = d.nodes; o->tris_tested = d.tris; o->exact_path_rays = d.exact;
+    if (reset) {
+        RT_HIP(hipMemset(r->ctl, 0, sizeof(Ctl)));
+        RT_HIP(hipMemset(r->counters, 0, sizeof(DCounters)));
+    }
+    return RT_OK;
+}
+extern "C" int rt_vpl_trace(rt_renderer* r, int n_vpls, uint64_t seed) {
+    if (!r || n_vpls < 0) { rt_set_error("rt_vpl_trace: bad argument"); return RT_ERR_INVALID; }
+    if (n_vpls > (1 << 20)) { rt_set_error("rt_vpl_trace: at most 2^20 light samples"); return RT_ERR_INVALID; }
+    RT_HIP(hipStreamSynchronize(r->stream));
+    r->n_vpl = 0; r->R.vpl_slots = 0;
+    if (n_vpls == 0) return RT_OK;
+    int rc;
+    float4* vpl = nullptr; float4* gather = nullptr;
+    if ((rc = dev_alloc(r, &vpl, (size_t)n_vpls * 6 * 4))) return rc;
+    if (!r->R.gather) { if ((rc = dev_alloc(r, &gather, (size_t)r->R.cap * 4))) return rc; r->R.gather = gather; }
+    r->R.vpl = vpl;
+    uint32_t* sp = nullptr;
+    int blocks = (n_vpls + 63) / 64;
+    if ((rc = dev_alloc(r, &sp, (size_t)blocks * 64 * std::max<uint32_t>(r->scene->host.max_stack2, 2)))) return rc;
+    LAUNCH(k_vpl_trace, blocks, 64, r->scene->d, r->R, n_vpls, seed, sp, r->ctl);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipStreamSynchronize(r->stream));
+    r->n_vpl = n_vpls; r->R.vpl_slots = (uint32_t)n_vpls * 6;
+    return RT_OK;
+}
+extern "C" int rt_vpl_count(const rt_renderer* r) {
+    if (!r || !r->R.vpl || r->R.vpl_slots == 0) return 0;
+    std::vector<float4> h((size_t)r->R.vpl_slots * 4);
+    if (hipMemcpy(h.data(), r->R.vpl, h.size() * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    int n = 0;
+    for (uint32_t v = 0; v < r->R.vpl_slots; v++) if (h[(size_t)v * 4 + 3].w != 0.0f) n++;
+    return n;
+}
+
+// Film::save (Imaging.h:278): Radiance RGBE of film / SPP (flat scanlines)
+extern "C" int rt_film_save_hdr(rt_renderer* r, const char* filename) {
+    if (!r || !filename) { rt_set_error("rt_film_save_hdr: NULL argument"); return RT_ERR_INVALID; }
+    std::vector<float> img((size_t)r->W * r->H * 3);
+    int spp = 0, rc = rt_film_read(r, img.data(), &spp);
+    if (rc) return rc;
+    FILE* f = fopen(filename, "wb");
+    if (!f) { rt_set_error(std::string("rt_film_save_hdr: cannot open ") + filename); return RT_ERR_INVALID; }
+    fprintf(f, "#?RADIANCE\n# Written by raytracer_amd\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=          1.0000000000000\n\n-Y %d +X %d\n", r->H, r->W);
+    std::vector<unsigned char> row((size_t)r->W * 4);
+    for (int y = 0; y < r->H; y++) {
+        for (int x = 0; x < r->W; x++) {
+            const float* p = &img[((size_t)y * r->W + x) * 3];
+            float c[3] = { p[0] / (float)spp, p[1] / (float)spp, p[2] / (float)spp };
+            float m = std::max(c[0], std::max(c[1], c[2]));
+            unsigned char* o = &row[(size_t)x * 4];
+            if (!(m > 1e-32f)) { o[0] = o[1] = o[2] = o[3] = 0; continue; }
+            int e; float norm = frexpf(m, &e) * 256.0f / m;
+            o[0] = (unsigned char)(c[0] * norm); o[1] = (unsigned char)(c[1] * norm); o[2] = (unsigned char)(c[2] * norm); o[3] = (unsigned char)(e + 128);
+        }
+        fwrite(row.data(), 1, row.size(), f);
+    }
+    fclose(f);
+    return RT_OK;
+}
+// Film::tonemap (Imaging.h:251)
+extern "C" int rt_film_tonemap(rt_renderer* r, uint8_t* rgb8) {
+    if (!r || !rgb8) { rt_set_error("rt_film_tonemap: NULL argument"); return RT_ERR_INVALID; }
+    std::vector<float> img((size_t)r->W * r->H * 3);
+    int spp = 0, rc = rt_film_read(r, img.data(), &spp);
+    if (rc) return rc;
+    for (size_t i = 0; i < img.size(); i++) {
+        float v = img[i] * 1.0f / (float)spp;
+        rgb8[i] = (uint8_t)std::min(powf(std::max(v, 0.0f), 1.0f / 2.2f) * 255, 255.0f);
+    }
+    return RT_OK;
+}
+
+static int debug_bsdf(rt_scene* s, uint32_t mat, const float* wo, const float* n, const float* uv, const uint32_t* kc, const float* wi, size_t count,
+                      float* out, int do_sample) {
+    if (!s || !wo || !n || !uv || !out || (do_sample ? !kc : !wi)) { rt_set_error("rt_debug_bsdf: NULL argument"); return RT_ERR_INVALID; }
+    if (mat >= s->host.mats.size()) { rt_set_error("rt_debug_bsdf: material out of range"); return RT_ERR_INVALID; }
+    if (count == 0) return RT_OK;
+    size_t ow = do_sample ? 7 : 4;
+    float *d_wo, *d_n, *d_uv, *d_x, *d_out;
+    RT_HIP(hipMalloc((void**)&d_wo, count * 12)); RT_HIP(hipMalloc((void**)&d_n, count * 12)); RT_HIP(hipMalloc((void**)&d_uv, count * 8));
+    RT_HIP(hipMalloc((void**)&d_x, count * 12)); RT_HIP(hipMalloc((void**)&d_out, count * ow * 4));
+    RT_HIP(hipMemcpy(d_wo, wo, count * 12, hipMemcpyHostToDevice)); RT_HIP(hipMemcpy(d_n, n, count * 12, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(d_uv, uv, count * 8, hipMemcpyHostToDevice));
+    if (do_sample) RT_HIP(hipMemcpy(d_x, kc, count * 8, hipMemcpyHostToDevice)); else RT_HIP(hipMemcpy(d_x, wi, count * 12, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_debug_bsdf, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, 0, s->d, mat, d_wo, d_n, d_uv, (const uint32_t*)d_x, d_x, count, d_out, do_sample);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpy(out, d_out, count * ow * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_wo); (void)hipFree(d_n); (void)hipFree(d_uv); (void)hipFree(d_x); (void)hipFree(d_out);
+    return RT_OK;
+}
+extern "C" int rt_debug_bsdf_sample(rt_scene* s, uint32_t mat, const float* wo, const float* n, const float* uv, const uint32_t* kc, size_t count, float* out) {
+    return debug_bsdf(s, mat, wo, n, uv, kc, nullptr, count, out, 1);
+}
+extern "C" int rt_debug_bsdf_eval(rt_scene* s, uint32_t mat, const float* wo, const float* n, const float* uv, const float* wi, size_t count, float* out) {
+    return debug_bsdf(s, mat, wo, n, uv, nullptr, wi, count, out, 0);
+}

@@ -36,6 +36,7 @@ __device__ __forceinline__ f3 norm3(f3 a) {                                     
 // std::max / std::min and the Windows max()/min() macros, NaN behaviour included
 __device__ __forceinline__ float smaxf(float a, float b) { return (a < b) ? b : a; }
 __device__ __forceinline__ float sminf(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float smaxf_w(float a, float b) { return (a > b) ? a : b; }  // max() macro of <Windows.h>
 
 struct col3 { float r, g, b; };
 __device__ __forceinline__ col3 mkc(float r, float g, float b) { col3 c; c.r = r; c.g = g; c.b = b; return c; }

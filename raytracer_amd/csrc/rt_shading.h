@@ -3,6 +3,7 @@
 // (Imaging.h:71).  Formulas are kept verbatim, quirks included; expressions that
 // the reference evaluates in double because of M_PI are evaluated in double here too.
 #pragma once
+#include "../../include/rtamd.h"
 #include "rt_device.h"
 
 #define RT_PI 3.14159265358979323846
