@@ -106,10 +106,11 @@ __device__ __forceinline__ bool camera_project(const DCamera& c, f3 p, float& x,
 }
 
 // ------------------------------------------------------------------------------------------------ control
-__global__ void k_ctl_reset(Ctl* ctl, int cur, int first, uint32_t first_count) {
+// `first`: the queue is the identity over `first_count` slots of which `first_live` hold a real path
+__global__ void k_ctl_reset(Ctl* ctl, int cur, int first, uint32_t first_count, uint32_t first_live) {
     ctl->tot_any += ctl->n_shadow;
     if (first) ctl->n_active[cur] = first_count;
-    ctl->tot_closest += ctl->n_active[cur];
+    ctl->tot_closest += first ? first_live : ctl->n_active[cur];
     ctl->n_active[cur ^ 1] = 0;
     for (int i = 0; i < 8; i++) ctl->n_class[i] = 0;
     ctl->n_shadow = 0;
@@ -791,14 +792,14 @@ static int render_path_like(rt_renderer* r, int mode, uint32_t batch, uint64_t s
     const bool radiosity = mode == RT_MODE_RADIOSITY && r->n_vpl > 0;
     const uint32_t n = R.np_pad * batch;
     LAUNCH(k_generate, r->flat_blocks, 256, S, R, n, seed, first_sample);
-    const int bounces = (mode == RT_MODE_DIRECT) ? 1 : RT_MAX_DEPTH + 2;
+    const int bounces = RT_MAX_DEPTH + 2;  // depth 0..5: the `depth > MAX_DEPTH` test sits after NEE (Renderer.h:233)
     for (int b = 0; b < bounces; b++) {
         int cur = b & 1;
-        LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n);
+        LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n, (uint32_t)r->W * r->H * batch);
         if (r->count_enabled) LAUNCH((k_extend<false, true>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
         else LAUNCH((k_extend<false, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
         if (radiosity) LAUNCH(k_shade<true>, r->flat_blocks, 256, S, R, r->ctl, cur, 0);
-        else LAUNCH(k_shade<false>, r->flat_blocks, 256, S, R, r->ctl, cur, mode == RT_MODE_DIRECT ? 1 : 0);
+        else LAUNCH(k_shade<false>, r->flat_blocks, 256, S, R, r->ctl, cur, 0);
         if (r->count_enabled) LAUNCH(k_connect<true>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
         else LAUNCH(k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
         if (radiosity) LAUNCH(k_gather, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2);
@@ -813,7 +814,7 @@ static int render_aov(rt_renderer* r, int mode, uint32_t batch, uint64_t seed, u
     const DScene& S = r->scene->d;
     RBuf& R = r->R;
     const uint32_t n = R.np_pad * batch;
-    LAUNCH(k_ctl_reset, 1, 1, r->ctl, 0, 1, n);
+    LAUNCH(k_ctl_reset, 1, 1, r->ctl, 0, 1, n, (uint32_t)r->W * r->H * batch);
     LAUNCH(k_aov, r->trav_blocks, RT_BLOCK, S, R, r->ctl, mode, seed, first_sample, n, r->spill4, r->spill2);
     LAUNCH(k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
     LAUNCH(k_ctl_final, 1, 1, r->ctl);
@@ -827,12 +828,12 @@ static int render_light(rt_renderer* r, uint32_t batch, uint64_t seed, uint64_t 
     RBuf& R = r->R;
     const uint32_t npix = (uint32_t)r->W * r->H;
     const uint32_t n = npix * batch;  // W*H light paths per spp (Renderer.h:331-337)
-    LAUNCH(k_ctl_reset, 1, 1, r->ctl, 0, 1, n);
+    LAUNCH(k_ctl_reset, 1, 1, r->ctl, 0, 1, 0u, 0u);
     LAUNCH(k_lt_generate, r->flat_blocks, 256, S, R, r->ctl, n, npix, seed, first_sample);
     LAUNCH(k_connect_camera, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->spill4, r->spill2);
     for (int b = 0; b < RT_MAX_DEPTH + 2; b++) {
         int cur = b & 1;
-        LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n);
+        LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n, n);
         LAUNCH((k_extend<true, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
         LAUNCH(k_lt_shade, r->flat_blocks, 256, S, R, r->ctl, cur);
         LAUNCH(k_connect_camera, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->spill4, r->spill2);
@@ -857,7 +858,7 @@ extern "C" int rt_render(rt_renderer* r, int mode, int spp, uint64_t seed, uint6
         uint32_t b = std::min<uint32_t>(bmax, (uint32_t)(spp - done));
         int rc;
         if (mode == RT_MODE_LIGHT) rc = render_light(r, b, seed, first_sample + done);
-        else if (mode == RT_MODE_AOV_ALBEDO || mode == RT_MODE_AOV_NORMAL) rc = render_aov(r, mode, b, seed, first_sample + done);
+        else if (mode == RT_MODE_AOV_ALBEDO || mode == RT_MODE_AOV_NORMAL || mode == RT_MODE_DIRECT) rc = render_aov(r, mode, b, seed, first_sample + done);
         else rc = render_path_like(r, mode, b, seed, first_sample + done);
         if (rc) return rc;
         done += (int)b;
