@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s and ms per spp, bathroom-class scene, 1920x1080 path tracing (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step is one sample per pixel of the whole frame (2 073 600 paths, <= 6 bounces each, NEE shadow rays).
+Inputs (BVH, triangles, materials, film, path state) are resident in HBM before the timed region.  With N > 1
+each rank renders its own K-spp slice of the sample-index space on a full scene replica (weak scaling) and the
+accumulation films are summed with one RCCL all-reduce over xGMI inside the timed region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+NODE_BYTES, TRI_BYTES = 128, 64
+# k_extend per ray besides node/triangle fetches: ray_o + ray_d (32) + thr (16) + hit write (16) + queue read/write (8)
+EXTEND_FIXED_BYTES = 72
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--detail", type=float, default=1.0, help="scene tessellation (1.0 = ~1.1 M triangles)")
+    ap.add_argument("--scene", default="bathroom")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-spp", type=int, default=1)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs WORLD_SIZE={a.gpus} (launch with torch.distributed.run); got {world}")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from raytracer_amd import api, scenes
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    if api.lib().rt_device_set(local_rank) != 0:
+        raise SystemExit("rt_device_set failed: " + api.lib().rt_last_error().decode())
+
+    W, H = 1920, 1080
+    sdata = scenes.interior(a.scene, a.detail, W, H, seed=1)
+    scene = api.Scene(sdata)
+    info = scene.info()
+    rt = api.RayTracer(scene)
+    film = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)  # film memory owned by torch so RCCL can reduce it
+    torch.cuda.synchronize()
+    rt.bind_film(film.data_ptr())
+
+    K, Wm = a.steps, a.warmup
+    seed = 1
+    # every rank owns a disjoint range of global sample indices: rank r renders [r*(Wm+K), (r+1)*(Wm+K))
+    base = rank * (Wm + K)
+    if Wm > 0:
+        rt.render(api.PATH, Wm, seed, base)
+    rt.sync()
+    rt.clear()
+    rt.counters(reset=True)
+    rt.profile_enable(True)
+    rt.profile(reset=True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    rt.render(api.PATH, K, seed, base + Wm)
+    rt.sync()
+    if world > 1:
+        dist.all_reduce(film)  # RCCL sum of the accumulation films (W*H*3 fp32), once per render
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = rt.profile(reset=True)
+    rt.profile_enable(False)
+    cnt = rt.counters(reset=True)
+    rays = cnt["closest_rays"] + cnt["any_rays"]
+
+    tt = torch.tensor([dt, float(rays), float(cnt["closest_rays"])], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_max, rays_all = float(tmax[0]), float(tsum[1])
+    else:
+        dt_max, rays_all = dt, float(rays)
+    spp_total = K * world
+    film_mean = float(film.mean()) / max(spp_total if world > 1 else K, 1)
+
+    out = None
+    if rank == 0:
+        # algorithmic bytes per closest-hit ray on this workload: counted (untimed) pass over the same samples
+        scene.counters_enable(True)
+        rt2 = api.RayTracer(scene)
+        rt2.render(api.PATH, 1, seed, base + Wm)
+        c2 = rt2.counters(reset=True)
+        scene.counters_enable(False)
+        rt2.close()
+        total2 = c2["closest_rays"] + c2["any_rays"]
+        nodes_per_ray = c2["nodes_visited"] / max(total2, 1)
+        tris_per_ray = c2["tris_tested"] / max(total2, 1)
+        bytes_per_ray = EXTEND_FIXED_BYTES + nodes_per_ray * NODE_BYTES + tris_per_ray * TRI_BYTES
+        ext_ms, ext_n = prof["extend"]
+        con_ms, con_n = prof["connect"]
+        # dominant kernel = k_extend; its rays over the timed region = closest_rays
+        ext_bytes = cnt["closest_rays"] * bytes_per_ray
+        achieved = ext_bytes / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("k_extend_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s (closest + any-hit rays issued / wall time of render); ms_per_step = ms per spp, bathroom-class 1080p",
+            "value": rays_all / dt_max / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": Wm,
+            "ms_per_step": dt_max * 1e3 / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{sdata.name} procedural stand-in, {info['n_tris']} triangles, {W}x{H}, path tracing (RT_MODE_PATH), "
+                            f"1 spp per step, {K} spp per rank",
+                "triangles": info["n_tris"], "width": W, "height": H, "spp_per_rank": K,
+                "parallelism": f"sample-partition x{world}" + (", RCCL film all-reduce" if world > 1 else ""),
+                "rays_per_pixel_sample": rays / (W * H * K),
+                "film_mean": film_mean,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_extend<false,false> (closest-hit 4-wide BVH walk)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "bytes_per_ray": bytes_per_ray,
+                "nodes_per_ray": nodes_per_ray,
+                "tris_per_ray": tris_per_ray,
+                "launches": ext_n,
+                "avg_launch_ms": ext_ms / max(ext_n, 1),
+                "note": "algorithmic bytes (every node/triangle fetch counted, cache hits included) / HIP-event time of k_extend",
+            },
+            "kernel_ms": {k: v[0] for k, v in prof.items()},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(sdata, a.cpu_spp)
+    rt.close()
+    scene.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(sdata, spp):
+    """The CPU oracle (oracle/rt_oracle.c: the reference's pointer-BVH recursive traversal + path tracer, restated)
+    on the host cores of this box, same scene and resolution, bounded to `spp` samples per pixel."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    o = orc.OracleScene(sdata)
+    t = time.perf_counter()
+    _, st = o.render(0, spp, seed=1, first_sample=0, threads=threads)
+    dt = time.perf_counter() - t
+    rays = st["closest_rays"] + st["any_rays"]
+    o.close()
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{spp} spp of the same {sdata.width}x{sdata.height} frame ({rays} rays, {dt:.1f} s), gcc -O2 -ffp-contract=off",
+            "ms_per_spp": dt * 1e3 / spp}
+
+
+if __name__ == "__main__":
+    main()

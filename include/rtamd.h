@@ -161,6 +161,11 @@ int rt_vpl_count(const rt_renderer* r);
 /* Rays issued / node + triangle fetches by rt_render since the last reset. */
 int rt_render_counters(rt_renderer* r, rt_counters* out, int reset);
 int rt_renderer_sync(rt_renderer* r);
+/* Per-kernel timing: HIP events recorded on the renderer's own stream around every launch of rt_render.
+ * ms7/launches7 index: 0 generate, 1 extend (closest hit), 2 shade, 3 connect (any hit), 4 VPL gather,
+ * 5 film accumulate, 6 control.  No counterpart upstream (Main.cpp:118 times render() with a wall clock). */
+int rt_profile_enable(rt_renderer* r, int enable);
+int rt_profile_read(rt_renderer* r, double* ms7, uint32_t* launches7, int reset);
 /* Film::save (Imaging.h:278): Radiance .hdr of film/SPP; Film::tonemap (Imaging.h:251) to 8-bit RGB. */
 int rt_film_save_hdr(rt_renderer* r, const char* filename);
 int rt_film_tonemap(rt_renderer* r, uint8_t* rgb8);

@@ -52,7 +52,7 @@ SYMBOLS = [
     "rt_intersect_any", "rt_intersect_any_dev", "rt_generate_rays", "rt_counters_enable", "rt_counters_read",
     "rt_renderer_create", "rt_renderer_destroy", "rt_render", "rt_film_clear", "rt_film_spp", "rt_film_read", "rt_film_bind",
     "rt_film_set_spp", "rt_vpl_trace", "rt_vpl_count", "rt_render_counters", "rt_renderer_sync", "rt_film_save_hdr",
-    "rt_film_tonemap", "rt_debug_bsdf_sample", "rt_debug_bsdf_eval", "rt_debug_rng",
+    "rt_film_tonemap", "rt_profile_enable", "rt_profile_read", "rt_debug_bsdf_sample", "rt_debug_bsdf_eval", "rt_debug_rng",
 ]
 
 
@@ -105,6 +105,8 @@ def lib():
         _sig(L, "rt_vpl_count", [vp])
         _sig(L, "rt_render_counters", [vp, C.POINTER(Counters), i32])
         _sig(L, "rt_renderer_sync", [vp])
+        _sig(L, "rt_profile_enable", [vp, i32])
+        _sig(L, "rt_profile_read", [vp, vp, vp, i32])
         _sig(L, "rt_film_save_hdr", [vp, C.c_char_p])
         _sig(L, "rt_film_tonemap", [vp, vp])
         _sig(L, "rt_debug_bsdf_sample", [vp, C.c_uint32, vp, vp, vp, vp, sz, vp])
@@ -284,6 +286,18 @@ class RayTracer:
         c = Counters()
         _check(self.L.rt_render_counters(self.h, C.byref(c), 1 if reset else 0), "rt_render_counters")
         return c.asdict()
+
+    KERNELS = ("generate", "extend", "shade", "connect", "gather", "accumulate", "control")
+
+    def profile_enable(self, on=True):
+        _check(self.L.rt_profile_enable(self.h, 1 if on else 0), "rt_profile_enable")
+
+    def profile(self, reset=True):
+        """{kernel: (total ms, launches)} from HIP events on the renderer's stream."""
+        ms = np.zeros(7, np.float64)
+        n = np.zeros(7, np.uint32)
+        _check(self.L.rt_profile_read(self.h, ms.ctypes.data, n.ctypes.data, 1 if reset else 0), "rt_profile_read")
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(self.KERNELS)}
 
     def saveHDR(self, filename):
         _check(self.L.rt_film_save_hdr(self.h, filename.encode()), "rt_film_save_hdr")

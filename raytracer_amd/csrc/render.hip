@@ -708,6 +708,7 @@ __global__ void k_debug_bsdf(DScene S, uint32_t mat, const float* wo, const floa
 }
 
 // ================================================================================================= host side
+enum { RT_KID_GENERATE = 0, RT_KID_EXTEND, RT_KID_SHADE, RT_KID_CONNECT, RT_KID_GATHER, RT_KID_ACCUMULATE, RT_KID_CTL, RT_KID_COUNT };
 struct rt_renderer {
     rt_scene* scene = nullptr;
     int W = 0, H = 0;
@@ -725,7 +726,16 @@ struct rt_renderer {
     int n_vpl = 0;
     bool count_enabled = false;
     std::vector<void*> allocs;
+    // per-kernel HIP-event timing on the renderer's own stream (rt_profile_enable)
+    bool profile = false;
+    struct ProfRec { int kid; hipEvent_t a, b; };
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> event_pool;
+    double prof_ms[RT_KID_COUNT] = { 0 };
+    uint32_t prof_launches[RT_KID_COUNT] = { 0 };
 };
+
+static void prof_collect(rt_renderer* r);
 
 template <class T>
 static int dev_alloc(rt_renderer* r, T** p, size_t count) {
@@ -739,7 +749,8 @@ static int dev_alloc(rt_renderer* r, T** p, size_t count) {
 
 extern "C" void rt_renderer_destroy(rt_renderer* r) {
     if (!r) return;
-    if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
+    if (r->stream) { (void)hipStreamSynchronize(r->stream); prof_collect(r); (void)hipStreamDestroy(r->stream); }
+    for (hipEvent_t e : r->event_pool) (void)hipEventDestroy(e);
     for (void* p : r->allocs) (void)hipFree(p);
     delete r;
 }
@@ -784,28 +795,52 @@ extern "C" int rt_renderer_create(rt_scene* scene, rt_renderer** out) {
     return RT_OK;
 }
 
-#define LAUNCH(kernel, blocks, threads, ...) hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), 0, r->stream, __VA_ARGS__)
+static hipEvent_t prof_event(rt_renderer* r) {
+    if (!r->event_pool.empty()) { hipEvent_t e = r->event_pool.back(); r->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+static void prof_collect(rt_renderer* r) {  // caller has synchronised the stream
+    for (auto& p : r->prof) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { r->prof_ms[p.kid] += ms; r->prof_launches[p.kid]++; }
+        r->event_pool.push_back(p.a); r->event_pool.push_back(p.b);
+    }
+    r->prof.clear();
+}
+#define LAUNCHK(kid, kernel, blocks, threads, ...)                                                   \
+    do {                                                                                             \
+        if (r->profile) {                                                                            \
+            rt_renderer::ProfRec pr_{ kid, prof_event(r), prof_event(r) };                           \
+            (void)hipEventRecord(pr_.a, r->stream);                                                  \
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), 0, r->stream, __VA_ARGS__);      \
+            (void)hipEventRecord(pr_.b, r->stream);                                                  \
+            r->prof.push_back(pr_);                                                                  \
+        } else hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), 0, r->stream, __VA_ARGS__);   \
+    } while (0)
+#define LAUNCH(kernel, blocks, threads, ...) LAUNCHK(RT_KID_CTL, kernel, blocks, threads, __VA_ARGS__)
 
 static int render_path_like(rt_renderer* r, int mode, uint32_t batch, uint64_t seed, uint64_t first_sample) {
     const DScene& S = r->scene->d;
     RBuf& R = r->R;
     const bool radiosity = mode == RT_MODE_RADIOSITY && r->n_vpl > 0;
     const uint32_t n = R.np_pad * batch;
-    LAUNCH(k_generate, r->flat_blocks, 256, S, R, n, seed, first_sample);
+    LAUNCHK(RT_KID_GENERATE, k_generate, r->flat_blocks, 256, S, R, n, seed, first_sample);
     const int bounces = RT_MAX_DEPTH + 2;  // depth 0..5: the `depth > MAX_DEPTH` test sits after NEE (Renderer.h:233)
     for (int b = 0; b < bounces; b++) {
         int cur = b & 1;
         LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n, (uint32_t)r->W * r->H * batch);
-        if (r->count_enabled) LAUNCH((k_extend<false, true>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
-        else LAUNCH((k_extend<false, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
-        if (radiosity) LAUNCH(k_shade<true>, r->flat_blocks, 256, S, R, r->ctl, cur, 0);
-        else LAUNCH(k_shade<false>, r->flat_blocks, 256, S, R, r->ctl, cur, 0);
-        if (r->count_enabled) LAUNCH(k_connect<true>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
-        else LAUNCH(k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
-        if (radiosity) LAUNCH(k_gather, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2);
+        if (r->count_enabled) LAUNCHK(RT_KID_EXTEND, (k_extend<false, true>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
+        else LAUNCHK(RT_KID_EXTEND, (k_extend<false, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
+        if (radiosity) LAUNCHK(RT_KID_SHADE, k_shade<true>, r->flat_blocks, 256, S, R, r->ctl, cur, 0);
+        else LAUNCHK(RT_KID_SHADE, k_shade<false>, r->flat_blocks, 256, S, R, r->ctl, cur, 0);
+        if (r->count_enabled) LAUNCHK(RT_KID_CONNECT, k_connect<true>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
+        else LAUNCHK(RT_KID_CONNECT, k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
+        if (radiosity) LAUNCHK(RT_KID_GATHER, k_gather, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2);
     }
     LAUNCH(k_ctl_final, 1, 1, r->ctl);
-    LAUNCH(k_accumulate, r->flat_blocks, 256, R, r->film, batch);
+    LAUNCHK(RT_KID_ACCUMULATE, k_accumulate, r->flat_blocks, 256, R, r->film, batch);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }
@@ -815,10 +850,10 @@ static int render_aov(rt_renderer* r, int mode, uint32_t batch, uint64_t seed, u
     RBuf& R = r->R;
     const uint32_t n = R.np_pad * batch;
     LAUNCH(k_ctl_reset, 1, 1, r->ctl, 0, 1, n, (uint32_t)r->W * r->H * batch);
-    LAUNCH(k_aov, r->trav_blocks, RT_BLOCK, S, R, r->ctl, mode, seed, first_sample, n, r->spill4, r->spill2);
-    LAUNCH(k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
+    LAUNCHK(RT_KID_EXTEND, k_aov, r->trav_blocks, RT_BLOCK, S, R, r->ctl, mode, seed, first_sample, n, r->spill4, r->spill2);
+    LAUNCHK(RT_KID_CONNECT, k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
     LAUNCH(k_ctl_final, 1, 1, r->ctl);
-    LAUNCH(k_accumulate, r->flat_blocks, 256, R, r->film, batch);
+    LAUNCHK(RT_KID_ACCUMULATE, k_accumulate, r->flat_blocks, 256, R, r->film, batch);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }
@@ -829,14 +864,14 @@ static int render_light(rt_renderer* r, uint32_t batch, uint64_t seed, uint64_t 
     const uint32_t npix = (uint32_t)r->W * r->H;
     const uint32_t n = npix * batch;  // W*H light paths per spp (Renderer.h:331-337)
     LAUNCH(k_ctl_reset, 1, 1, r->ctl, 0, 1, 0u, 0u);
-    LAUNCH(k_lt_generate, r->flat_blocks, 256, S, R, r->ctl, n, npix, seed, first_sample);
-    LAUNCH(k_connect_camera, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->spill4, r->spill2);
+    LAUNCHK(RT_KID_GENERATE, k_lt_generate, r->flat_blocks, 256, S, R, r->ctl, n, npix, seed, first_sample);
+    LAUNCHK(RT_KID_CONNECT, k_connect_camera, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->spill4, r->spill2);
     for (int b = 0; b < RT_MAX_DEPTH + 2; b++) {
         int cur = b & 1;
         LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n, n);
-        LAUNCH((k_extend<true, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
-        LAUNCH(k_lt_shade, r->flat_blocks, 256, S, R, r->ctl, cur);
-        LAUNCH(k_connect_camera, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->spill4, r->spill2);
+        LAUNCHK(RT_KID_EXTEND, (k_extend<true, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
+        LAUNCHK(RT_KID_SHADE, k_lt_shade, r->flat_blocks, 256, S, R, r->ctl, cur);
+        LAUNCHK(RT_KID_CONNECT, k_connect_camera, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->spill4, r->spill2);
     }
     LAUNCH(k_ctl_final, 1, 1, r->ctl);
     RT_HIP(hipGetLastError());
@@ -870,6 +905,24 @@ extern "C" int rt_render(rt_renderer* r, int mode, int spp, uint64_t seed, uint6
 extern "C" int rt_renderer_sync(rt_renderer* r) {
     if (!r) { rt_set_error("rt_renderer_sync: NULL"); return RT_ERR_INVALID; }
     RT_HIP(hipStreamSynchronize(r->stream));
+    prof_collect(r);
+    return RT_OK;
+}
+// Per-kernel timing with HIP events recorded on the renderer's stream around every launch.
+// kernel ids: 0 generate, 1 extend, 2 shade, 3 connect, 4 gather, 5 accumulate, 6 control
+extern "C" int rt_profile_enable(rt_renderer* r, int enable) {
+    if (!r) { rt_set_error("rt_profile_enable: NULL"); return RT_ERR_INVALID; }
+    RT_HIP(hipStreamSynchronize(r->stream));
+    prof_collect(r);
+    r->profile = enable != 0;
+    return RT_OK;
+}
+extern "C" int rt_profile_read(rt_renderer* r, double* ms7, uint32_t* launches7, int reset) {
+    if (!r || !ms7 || !launches7) { rt_set_error("rt_profile_read: NULL argument"); return RT_ERR_INVALID; }
+    RT_HIP(hipStreamSynchronize(r->stream));
+    prof_collect(r);
+    for (int i = 0; i < RT_KID_COUNT; i++) { ms7[i] = r->prof_ms[i]; launches7[i] = r->prof_launches[i]; }
+    if (reset) for (int i = 0; i < RT_KID_COUNT; i++) { r->prof_ms[i] = 0; r->prof_launches[i] = 0; }
     return RT_OK;
 }
 extern "C" int rt_film_clear(rt_renderer* r) {  // Film::clear (Imaging.h:269)
