@@ -103,7 +103,9 @@ def main():
     else:
         dt_max, rays_all = dt, float(rays)
     spp_total = K * world
-    film_mean = float(film.mean()) / max(spp_total if world > 1 else K, 1)
+    finite = torch.isfinite(film)
+    film_mean = float(film[finite].mean()) / max(spp_total if world > 1 else K, 1)
+    film_nan = int((~finite).sum())  # upstream's estimators can return inf/NaN (e.g. MirrorBSDF divides by wi.z, Materials.h:264)
 
     out = None
     if rank == 0:
@@ -114,9 +116,10 @@ def main():
         c2 = rt2.counters(reset=True)
         scene.counters_enable(False)
         rt2.close()
-        total2 = c2["closest_rays"] + c2["any_rays"]
-        nodes_per_ray = c2["nodes_visited"] / max(total2, 1)
-        tris_per_ray = c2["tris_tested"] / max(total2, 1)
+        nodes_per_ray = c2["nodes_visited"] / max(c2["closest_rays"], 1)
+        tris_per_ray = c2["tris_tested"] / max(c2["closest_rays"], 1)
+        any_nodes_per_ray = c2["any_nodes_visited"] / max(c2["any_rays"], 1)
+        any_tris_per_ray = c2["any_tris_tested"] / max(c2["any_rays"], 1)
         bytes_per_ray = EXTEND_FIXED_BYTES + nodes_per_ray * NODE_BYTES + tris_per_ray * TRI_BYTES
         ext_ms, ext_n = prof["extend"]
         con_ms, con_n = prof["connect"]
@@ -149,7 +152,7 @@ def main():
                 "triangles": info["n_tris"], "width": W, "height": H, "spp_per_rank": K,
                 "parallelism": f"sample-partition x{world}" + (", RCCL film all-reduce" if world > 1 else ""),
                 "rays_per_pixel_sample": rays / (W * H * K),
-                "film_mean": film_mean,
+                "film_mean": film_mean, "film_nonfinite_values": film_nan,
             },
             "roofline": {
                 "bound": "hbm",
@@ -167,6 +170,8 @@ def main():
                 "note": "algorithmic bytes (every node/triangle fetch counted, cache hits included) / HIP-event time of k_extend",
             },
             "kernel_ms": {k: v[0] for k, v in prof.items()},
+            "connect": {"nodes_per_ray": any_nodes_per_ray, "tris_per_ray": any_tris_per_ray,
+                        "rays": cnt["any_rays"], "ms": con_ms, "launches": con_n},
         }
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sdata, a.cpu_spp)

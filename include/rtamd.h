@@ -90,8 +90,9 @@ typedef struct {
 
 typedef struct {
     uint64_t closest_rays, any_rays;        /* rays issued (Scene::traverse / Scene::visible equivalents) */
-    uint64_t nodes_visited, tris_tested;    /* wide-node fetches (128 B each) and triangle-record fetches (64 B each) */
+    uint64_t nodes_visited, tris_tested;    /* closest-hit walks: wide-node fetches (128 B each) and triangle-record fetches (64 B each) */
     uint64_t exact_path_rays;               /* rays routed through the reference-order fallback walk */
+    uint64_t any_nodes_visited, any_tris_tested;  /* the same two counts for any-hit (Scene::visible) walks */
 } rt_counters;
 
 typedef struct rt_scene rt_scene;

@@ -88,8 +88,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_intersect_any(DScene S, const floa
         }
     }
     if (COUNT) {
-        atomicAdd(&counters->any, (unsigned long long)cr); atomicAdd(&counters->nodes, (unsigned long long)cn);
-        atomicAdd(&counters->tris, (unsigned long long)ct); atomicAdd(&counters->exact, (unsigned long long)cx);
+        atomicAdd(&counters->any, (unsigned long long)cr); atomicAdd(&counters->any_nodes, (unsigned long long)cn);
+        atomicAdd(&counters->any_tris, (unsigned long long)ct); atomicAdd(&counters->exact, (unsigned long long)cx);
     }
 }
 
@@ -243,6 +243,7 @@ extern "C" int rt_counters_read(rt_scene* s, rt_counters* o, int reset) {
     RT_HIP(hipDeviceSynchronize());
     RT_HIP(hipMemcpy(&c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     o->closest_rays = c.closest; o->any_rays = c.any; o->nodes_visited = c.nodes; o->tris_tested = c.tris; o->exact_path_rays = c.exact;
+    o->any_nodes_visited = c.any_nodes; o->any_tris_tested = c.any_tris;
     if (reset) RT_HIP(hipMemset(s->d_counters, 0, sizeof(DCounters)));
     return RT_OK;
 }

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_connect(DScene S, RBuf R, Ctl* ctl
         }
     }
     if (COUNT) {
-        atomicAdd(&counters->nodes, (unsigned long long)cn); atomicAdd(&counters->tris, (unsigned long long)ct);
+        atomicAdd(&counters->any_nodes, (unsigned long long)cn); atomicAdd(&counters->any_tris, (unsigned long long)ct);
         atomicAdd(&counters->exact, (unsigned long long)cx);
     }
 }
@@ -957,6 +957,7 @@ extern "C" int rt_render_counters(rt_renderer* r, rt_counters* o, int reset) {
     RT_HIP(hipMemcpy(&c, r->ctl, sizeof(c), hipMemcpyDeviceToHost));
     RT_HIP(hipMemcpy(&d, r->counters, sizeof(d), hipMemcpyDeviceToHost));
     o->closest_rays = c.tot_closest; o->any_rays = c.tot_any; o->nodes_visited = d.nodes; o->tris_tested = d.tris; o->exact_path_rays = d.exact;
+    o->any_nodes_visited = d.any_nodes; o->any_tris_tested = d.any_tris;
     if (reset) {
         RT_HIP(hipMemset(r->ctl, 0, sizeof(Ctl)));
         RT_HIP(hipMemset(r->counters, 0, sizeof(DCounters)));

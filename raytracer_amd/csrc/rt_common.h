@@ -93,4 +93,4 @@ struct DScene {
     DCamera cam;
 };
 
-struct DCounters { unsigned long long closest, any, nodes, tris, exact; };
+struct DCounters { unsigned long long closest, any, nodes, tris, exact, any_nodes, any_tris; };

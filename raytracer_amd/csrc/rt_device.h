@@ -242,6 +242,10 @@ __device__ __forceinline__ void rt_closest(const DScene& S, f3 o, f3 dir, int mo
                                            uint32_t* spill2, uint32_t gstride, uint32_t& cn, uint32_t& ct, uint32_t& cexact) {
     best.t = RT_FLT_MAX; best.u = 0; best.v = 0; best.rank = 0xFFFFFFFFu;
     if (S.root_ref == RT_REF_EMPTY) return;
+    // dir == (0,0,0) (what pathTrace shoots after a BSDF returned pdf 0 / wi 0, e.g. Materials.h:319-324): Dot(n, dir)
+    // is 0 for every triangle, so Triangle::rayIntersect rejects all of them (Geometry.h:118) -- a miss, whatever
+    // boxes the reference would have walked through on the way.
+    if (mode == 0 && dir.x == 0.0f && dir.y == 0.0f && dir.z == 0.0f) return;
     f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
     if (mode == 0 && rt_ray_is_tame(inv)) rt_walk_wide<false, COUNT>(S, o, dir, inv, 0.0f, best, st, cn, ct);
     else { if (COUNT) cexact++; rt_walk_reference<false, COUNT>(S, o, dir, 0.0f, best, spill2, gstride, cn, ct); }

@@ -53,4 +53,4 @@ for _ in range(a.reps):
     torch.cuda.synchronize(); t = time.perf_counter()
     sc.visible_dev(d_s.data_ptr(), len(segs), d_v.data_ptr(), 0)
     torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
-print(f"shadow any-hit: {len(segs)/min(ts)/1e6:9.1f} Mrays/s nodes/ray {c['nodes_visited']/len(segs):.1f} tris/ray {c['tris_tested']/len(segs):.1f}", flush=True)
+print(f"shadow any-hit: {len(segs)/min(ts)/1e6:9.1f} Mrays/s nodes/ray {c['any_nodes_visited']/len(segs):.1f} tris/ray {c['any_tris_tested']/len(segs):.1f}", flush=True)
