@@ -17,7 +17,7 @@ from .abi import Camera, HIT_DTYPE, Marshalled, SceneDesc
 from .scenes import SceneData
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtamd.so")
+LIB_PATH = os.environ.get("RT_LIB", os.path.join(_HERE, "librtamd.so"))  # RT_LIB: A/B builds of the same HIP library
 
 PATH, LIGHT, MLT, RADIOSITY, PATH_ST, AOV_ALBEDO, AOV_NORMAL, DIRECT = 0, 1, 2, 4, 5, 10, 11, 12
 

@@ -4,6 +4,7 @@
 // 64-ray chunks from a device work counter until the batch is drained, so a wave that finishes a cheap
 // chunk immediately takes more work and ray order (hence BVH/L2 locality of neighbouring rays) is kept.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "rt_device.h"
@@ -41,9 +42,9 @@ template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_intersect_closest(DScene S, const float* __restrict__ rays, unsigned long long n,
                                                                 rt_hit* __restrict__ out, int mode, unsigned long long* work,
                                                                 uint32_t* spill4, uint32_t* spill2, DCounters* counters) {
-    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    __shared__ uint32_t lds_stack[RT_STACK_WORDS];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
-    TravStack st; st.lds = lds_stack + threadIdx.x; st.glob = spill4 ? spill4 + gtid : nullptr; st.gstride = gstride;
+    RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
     uint32_t cn = 0, ct = 0, cx = 0, cr = 0;
     for (;;) {
         unsigned long long base = rt_fetch_chunk(work);
@@ -72,9 +73,9 @@ template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_intersect_any(DScene S, const float* __restrict__ segs, unsigned long long n,
                                                             uint8_t* __restrict__ out, int mode, unsigned long long* work,
                                                             uint32_t* spill4, uint32_t* spill2, DCounters* counters) {
-    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    __shared__ uint32_t lds_stack[RT_STACK_WORDS];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
-    TravStack st; st.lds = lds_stack + threadIdx.x; st.glob = spill4 ? spill4 + gtid : nullptr; st.gstride = gstride;
+    RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
     uint32_t cn = 0, ct = 0, cx = 0, cr = 0;
     for (;;) {
         unsigned long long base = rt_fetch_chunk(work);
@@ -156,6 +157,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
     d.root_ref = d.n_tris ? 0u : RT_REF_EMPTY;
     d.max_stack4 = h.max_stack4; d.max_stack2 = h.max_stack2;
     d.abs_max = h.abs_max;
+    d.variant = getenv("RT_VARIANT") ? atoi(getenv("RT_VARIANT")) : 0;
     memcpy(d.bg_colour, h.bg_colour, 12); d.bg_kind = h.bg_kind; d.bg_tex = h.bg_tex;
     memcpy(d.scene_centre, h.centre, 12); d.scene_radius = h.radius;
 
@@ -169,7 +171,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
     size_t threads = (size_t)s->persistent_blocks * RT_BLOCK;
     void* p = nullptr;
     if (h.max_stack4 > RT_STACK_LDS) {
-        size_t bytes = threads * (h.max_stack4 - RT_STACK_LDS) * sizeof(uint32_t);
+        size_t bytes = threads * (h.max_stack4 - RT_STACK_LDS) * sizeof(uint32_t) * (RT_STACK_KEYS ? 2 : 1);
         if (hipMalloc(&p, bytes) != hipSuccess) { rt_set_error("rt_scene_create: out of device memory (stack spill)"); return fail(RT_ERR_NOMEM); }
         s->allocs.push_back(p); s->device_bytes += bytes; s->d_spill4 = (uint32_t*)p;
     }

@@ -28,6 +28,7 @@ struct Ctl {
     uint32_t n_gather;
     unsigned long long work[4];  // extend, shade, connect, gather
     unsigned long long tot_closest, tot_any;
+    unsigned long long work_x[2][8][16];  // [extend|connect][XCD shard], one 128-B line each
 };
 
 struct RBuf {  // device buffers of one renderer
@@ -47,6 +48,71 @@ __device__ __forceinline__ unsigned long long fetch_chunk(unsigned long long* wo
     unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
     unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
     return ((unsigned long long)hi << 32) | lo;
+}
+// A wave takes RT_FETCH_CHUNKS x 64 consecutive items per atomic: one contended device-scope atomic costs ~11 ns
+// (MI355X_MICROARCH.md "fanin"/"dequeue"), so per-64-item fetches alone would cap a kernel at ~5.8 G items/s.
+#define RT_FETCH_CHUNKS 4
+__device__ __forceinline__ unsigned long long fetch_chunks(unsigned long long* work, unsigned chunks) {
+    unsigned long long base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(work, 64ULL * chunks);
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
+    unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+#ifndef RT_XCD_SHARD
+#define RT_XCD_SHARD 1
+#endif
+// XCD-aware work distribution: the item range is cut into 8 contiguous shards, one per XCD (HW_REG_XCC_ID); a wave
+// drains its own XCD's shard first and then steals from the others.  Queues keep pixel/path order through
+// compaction, so a shard is a spatially coherent part of the frame and its BVH working set stays in that XCD's 4 MB
+// L2 instead of being replicated in all eight.  Placement only affects speed, never results.
+struct XcdFetch {
+    uint32_t xcc, step, per;
+    __device__ __forceinline__ void init(uint32_t n) {
+        xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;  // HW_REG_XCC_ID[3:0]
+        step = 0;
+        uint32_t unit = 64u * RT_FETCH_CHUNKS;
+        per = (((n + 7u) / 8u + unit - 1u) / unit) * unit;
+    }
+    // returns false when every shard is exhausted; otherwise [base, end) with base a multiple of 64
+    __device__ __forceinline__ bool next(unsigned long long (*w)[16], uint32_t n, uint32_t& base, uint32_t& end) {
+        while (step < 8) {
+            uint32_t sh = RT_XCD_SHARD ? ((xcc + step) & 7u) : step;
+            unsigned long long lo = (unsigned long long)sh * per, hi = lo + per;
+            if (hi > n) hi = n;
+            if (lo < hi) {
+                unsigned long long b = 0;
+                if ((threadIdx.x & 63) == 0) b = atomicAdd(&w[sh][0], 64ULL * RT_FETCH_CHUNKS);
+                uint32_t b32 = __builtin_amdgcn_readfirstlane((unsigned)b);
+                if (lo + b32 < hi) { base = (uint32_t)lo + b32; end = (uint32_t)hi; return true; }
+            }
+            step++;
+        }
+        return false;
+    }
+};
+// Block-wide append to NQ queues: per-wave ballots, an LDS scan over the waves, ONE global atomic per queue per
+// block iteration.  All threads of the block must call it (it contains barriers).  smem: NQ*(NW+1) words.
+template <int NQ, int NW>
+__device__ __forceinline__ void block_append(uint32_t* const (&counters)[NQ], const bool (&pred)[NQ], uint32_t (&slot)[NQ], uint32_t* smem) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t prefix[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        unsigned long long mask = __ballot(pred[q]);
+        prefix[q] = (uint32_t)__popcll(mask & ((1ULL << lane) - 1ULL));
+        if (lane == 0) smem[q * (NW + 1) + wave] = (uint32_t)__popcll(mask);
+    }
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+        const int q = threadIdx.x;
+        uint32_t sum = 0;
+        for (int w = 0; w < NW; w++) { uint32_t c = smem[q * (NW + 1) + w]; smem[q * (NW + 1) + w] = sum; sum += c; }
+        smem[q * (NW + 1) + NW] = sum ? atomicAdd(counters[q], sum) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; q++) slot[q] = smem[q * (NW + 1) + NW] + smem[q * (NW + 1) + wave] + prefix[q];
 }
 // ballot + prefix-sum append: one atomic per wave, slots handed out in lane order
 __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
@@ -116,6 +182,7 @@ __global__ void k_ctl_reset(Ctl* ctl, int cur, int first, uint32_t first_count, 
     ctl->n_shadow = 0;
     ctl->n_gather = 0;
     for (int i = 0; i < 4; i++) ctl->work[i] = 0;
+    for (int k = 0; k < 2; k++) for (int i = 0; i < 8; i++) ctl->work_x[k][i][0] = 0;
 }
 __global__ void k_ctl_final(Ctl* ctl) {
     ctl->tot_any += ctl->n_shadow;
@@ -145,56 +212,101 @@ __global__ __launch_bounds__(256) void k_generate(DScene S, RBuf R, uint32_t n, 
 // Scene::traverse for every live path + the two trivial outcomes of pathTrace handled in place:
 // escaped rays add background->evaluate(dir) un-weighted (Renderer.h:254) and emitters add T*Le only when
 // canHitLight (Renderer.h:221-231).  Everything else is binned by BSDF class for the shade kernel.
+#ifndef RT_EXTEND_STAGE
+#define RT_EXTEND_STAGE 0   // measured: per-wave LDS staging of the class queues is slower than one atomic per class per chunk
+#endif
+#define RT_STAGE 128   // per-wave, per-class staging slots in LDS (flushed 64 at a time)
 template <bool LT, bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene S, RBuf R, Ctl* ctl, int cur, int first, uint32_t* spill4, uint32_t* spill2,
+__global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_extend(DScene S, RBuf R, Ctl* ctl, int cur, int first, uint32_t* spill4, uint32_t* spill2,
                                                      DCounters* counters) {
-    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    __shared__ uint32_t lds_stack[RT_STACK_WORDS];
+    // survivors are staged per wave and per BSDF class in LDS and flushed 64 at a time: one queue atomic and one
+    // coalesced 256-B store per 64 paths instead of one atomic per class per 64-ray chunk
+#if RT_EXTEND_STAGE
+    __shared__ uint32_t lds_stage[(RT_BLOCK / 64) * RT_NCLASS * RT_STAGE];
+#else
+    uint32_t* lds_stage = nullptr;
+#endif
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
-    TravStack st; st.lds = lds_stack + threadIdx.x; st.glob = spill4 ? spill4 + gtid : nullptr; st.gstride = gstride;
+    const uint32_t lane = threadIdx.x & 63;
+    RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
+    uint32_t* stage = lds_stage + (threadIdx.x >> 6) * (RT_NCLASS * RT_STAGE);
+    constexpr int NC = LT ? 1 : RT_NCLASS;
+    uint32_t staged[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) staged[c] = 0;
     const uint32_t n = ctl->n_active[cur];
     const uint32_t* queue = R.q_active[cur];
     uint32_t cn = 0, ct = 0, cx = 0;
+    XcdFetch xf; xf.init(n);
     for (;;) {
-        unsigned long long base = fetch_chunk(&ctl->work[0]);
-        if (base >= n) break;
-        uint32_t i = (uint32_t)base + (threadIdx.x & 63);
-        int cls = -1;
-        uint32_t path = 0;
-        if (i < n) {
-            path = first ? i : queue[i];
-            float4 th = R.thr[path];
-            uint32_t flags = __float_as_uint(th.w);
-            if (!(flags & RT_FLAG_DEAD)) {
-                float4 ro = R.ray_o[path], rd = R.ray_d[path];
-                f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
-                HitRec h;
-                rt_closest<COUNT>(S, o, d, 0, h, st, spill2 + gtid, gstride, cn, ct, cx);
-                if (h.t < RT_FLT_MAX) {
-                    uint32_t mat = S.tris[h.rank].mat_gsign & 0x7FFFFFFFu;
-                    const DMaterial& m = S.mats[mat];
-                    if (!LT && (m.flags & RT_MF_LIGHT)) {
-                        if (flags & RT_FLAG_CANHIT) {
-                            float4 L = R.rad[path];
-                            col3 c = mkc(th.x, th.y, th.z) * mat_emission(m);
-                            R.rad[path] = make_float4(L.x + c.r, L.y + c.g, L.z + c.b, L.w);
+        uint32_t base0, end0;
+        if (!xf.next(ctl->work_x[0], n, base0, end0)) break;
+        for (unsigned g = 0; g < RT_FETCH_CHUNKS; g++) {
+            uint32_t base = base0 + 64u * g;
+            if (base >= end0) break;
+            uint32_t i = base + lane;
+            int cls = -1;
+            uint32_t path = 0;
+            if (i < end0) {
+                path = first ? i : queue[i];
+                float4 th = R.thr[path];
+                uint32_t flags = __float_as_uint(th.w);
+                if (!(flags & RT_FLAG_DEAD)) {
+                    float4 ro = R.ray_o[path], rd = R.ray_d[path];
+                    f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
+                    HitRec h;
+                    rt_closest<COUNT>(S, o, d, 0, h, st, spill2 + gtid, gstride, cn, ct, cx);
+                    if (h.t < RT_FLT_MAX) {
+                        uint32_t mat = S.tris[h.rank].mat_gsign & 0x7FFFFFFFu;
+                        const DMaterial& m = S.mats[mat];
+                        if (!LT && (m.flags & RT_MF_LIGHT)) {
+                            if (flags & RT_FLAG_CANHIT) {
+                                float4 L = R.rad[path];
+                                col3 c = mkc(th.x, th.y, th.z) * mat_emission(m);
+                                R.rad[path] = make_float4(L.x + c.r, L.y + c.g, L.z + c.b, L.w);
+                            }
+                        } else {
+                            R.hit[path] = make_float4(h.t, h.u, h.v, __uint_as_float(h.rank));
+                            cls = LT ? 0 : class_of(m.type);
                         }
-                    } else {
-                        R.hit[path] = make_float4(h.t, h.u, h.v, __uint_as_float(h.rank));
-                        cls = LT ? 0 : class_of(m.type);
+                    } else if (!LT) {
+                        float4 L = R.rad[path];
+                        col3 c = bg_evaluate(S, d);
+                        R.rad[path] = make_float4(L.x + c.r, L.y + c.g, L.z + c.b, L.w);
                     }
-                } else if (!LT) {
-                    float4 L = R.rad[path];
-                    col3 c = bg_evaluate(S, d);
-                    R.rad[path] = make_float4(L.x + c.r, L.y + c.g, L.z + c.b, L.w);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                bool mine = cls == c;
+#if !RT_EXTEND_STAGE
+                { uint32_t slot = wave_append(&ctl->n_class[c], mine); if (mine) R.q_class[(size_t)c * R.cap + slot] = path; continue; }
+#endif
+                unsigned long long mask = __ballot(mine);
+                if (mask == 0) continue;
+                uint32_t* buf = stage + c * RT_STAGE;
+                if (mine) buf[staged[c] + (uint32_t)__popcll(mask & ((1ULL << lane) - 1ULL))] = path;
+                staged[c] += (uint32_t)__popcll(mask);
+                if (staged[c] >= 64) {  // flush one full wave-width
+                    uint32_t qb = 0;
+                    if (lane == 0) qb = atomicAdd(&ctl->n_class[c], 64u);
+                    qb = __builtin_amdgcn_readfirstlane(qb);
+                    R.q_class[(size_t)c * R.cap + qb + lane] = buf[lane];
+                    uint32_t tail = buf[64 + lane];
+                    buf[lane] = tail;
+                    staged[c] -= 64;
                 }
             }
         }
+    }
 #pragma unroll
-        for (int c = 0; c < (LT ? 1 : RT_NCLASS); c++) {
-            bool mine = cls == c;
-            uint32_t slot = wave_append(&ctl->n_class[c], mine);
-            if (mine) R.q_class[(size_t)c * R.cap + slot] = path;
-        }
+    for (int c = 0; c < NC; c++) {
+        if (staged[c] == 0) continue;
+        uint32_t qb = 0;
+        if (lane == 0) qb = atomicAdd(&ctl->n_class[c], staged[c]);
+        qb = __builtin_amdgcn_readfirstlane(qb);
+        if (lane < staged[c]) R.q_class[(size_t)c * R.cap + qb + lane] = stage[c * RT_STAGE + lane];
     }
     if (COUNT) {
         atomicAdd(&counters->nodes, (unsigned long long)cn); atomicAdd(&counters->tris, (unsigned long long)ct);
@@ -206,15 +318,21 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene S, RBuf R, Ctl* ctl,
 // Body of pathTrace after the hit (Renderer.h:232-252): NEE request (computeDirect, Renderer.h:155), depth
 // test, Russian roulette, BSDF sample, throughput update, next ray.  RADIOSITY adds the VPL gather request of
 // pathTraceRadiosity (Renderer.h:931).
+#define RT_SHADE_BLOCK 512
 template <bool RADIOSITY>
-__global__ __launch_bounds__(256) void k_shade(DScene S, RBuf R, Ctl* ctl, int cur, int direct_only) {
+__global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene S, RBuf R, Ctl* ctl, int cur, int direct_only) {
+    __shared__ unsigned long long s_base;
+    __shared__ uint32_t s_app[3 * (RT_SHADE_BLOCK / 64 + 1)];
     uint32_t cnt[RT_NCLASS], total = 0;
 #pragma unroll
     for (int c = 0; c < RT_NCLASS; c++) { cnt[c] = ctl->n_class[c]; total += cnt[c]; }
     for (;;) {
-        unsigned long long base = fetch_chunk(&ctl->work[1]);
+        // the block moves in lockstep: one work atomic and one atomic per output queue per 512 shading points
+        if (threadIdx.x == 0) s_base = atomicAdd(&ctl->work[1], (unsigned long long)RT_SHADE_BLOCK);
+        __syncthreads();
+        unsigned long long base = s_base;
         if (base >= total) break;
-        uint32_t g = (uint32_t)base + (threadIdx.x & 63);
+        uint32_t g = (uint32_t)base + threadIdx.x;
         bool live = g < total;
         bool want_next = false, want_shadow = false, want_gather = false;
         uint32_t path = 0;
@@ -298,31 +416,32 @@ __global__ __launch_bounds__(256) void k_shade(DScene S, RBuf R, Ctl* ctl, int c
                 }
             }
         }
-        uint32_t s1 = wave_append(&ctl->n_shadow, want_shadow);
-        if (want_shadow) { float4* e = R.shadow + (size_t)s1 * 3; e[0] = sh_a; e[1] = sh_b; e[2] = sh_c; }
-        if (RADIOSITY) {
-            uint32_t s2 = wave_append(&ctl->n_gather, want_gather);
-            if (want_gather) { float4* e = R.gather + (size_t)s2 * 4; e[0] = ga; e[1] = gb; e[2] = gc; e[3] = gd; }
-        }
-        uint32_t s3 = wave_append(&ctl->n_active[cur ^ 1], want_next);
-        if (want_next) R.q_active[cur ^ 1][s3] = path;
+        uint32_t* const counters[3] = { &ctl->n_shadow, &ctl->n_active[cur ^ 1], &ctl->n_gather };
+        const bool pred[3] = { want_shadow, want_next, RADIOSITY && want_gather };
+        uint32_t slot[3];
+        block_append<3, RT_SHADE_BLOCK / 64>(counters, pred, slot, s_app);
+        if (want_shadow) { float4* e = R.shadow + (size_t)slot[0] * 3; e[0] = sh_a; e[1] = sh_b; e[2] = sh_c; }
+        if (want_next) R.q_active[cur ^ 1][slot[1]] = path;
+        if (RADIOSITY && want_gather) { float4* e = R.gather + (size_t)slot[2] * 4; e[0] = ga; e[1] = gb; e[2] = gc; e[3] = gd; }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ connect
 // Scene::visible for every NEE request; visible ones add their (already throughput-weighted) term.
 template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_connect(DScene S, RBuf R, Ctl* ctl, uint32_t* spill4, uint32_t* spill2, DCounters* counters) {
-    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+__global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_connect(DScene S, RBuf R, Ctl* ctl, uint32_t* spill4, uint32_t* spill2, DCounters* counters) {
+    __shared__ uint32_t lds_stack[RT_STACK_WORDS];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
-    TravStack st; st.lds = lds_stack + threadIdx.x; st.glob = spill4 ? spill4 + gtid : nullptr; st.gstride = gstride;
+    RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
     const uint32_t n = ctl->n_shadow;
     uint32_t cn = 0, ct = 0, cx = 0;
+    XcdFetch xf; xf.init(n);
     for (;;) {
-        unsigned long long base = fetch_chunk(&ctl->work[2]);
-        if (base >= n) break;
-        uint32_t i = (uint32_t)base + (threadIdx.x & 63);
-        if (i < n) {
+        uint32_t base0, end0;
+        if (!xf.next(ctl->work_x[1], n, base0, end0)) break;
+        for (unsigned g = 0; g < RT_FETCH_CHUNKS; g++) {
+        uint32_t i = base0 + 64u * g + (threadIdx.x & 63);
+        if (i < end0) {
             const float4* e = R.shadow + (size_t)i * 3;
             float4 a = e[0], b = e[1];
             if (rt_visible<COUNT>(S, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), 0, st, spill2 + gtid, gstride, cn, ct, cx)) {
@@ -331,6 +450,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_connect(DScene S, RBuf R, Ctl* ctl
                 float4 L = R.rad[path];
                 R.rad[path] = make_float4(L.x + c.x, L.y + c.y, L.z + c.z, L.w);
             }
+        }
         }
     }
     if (COUNT) {
@@ -341,9 +461,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_connect(DScene S, RBuf R, Ctl* ctl
 
 // connectToCamera (Renderer.h:669-692): projection, visibility to the lens, We = 1/(Afilm cos^4), atomic splat
 __global__ __launch_bounds__(RT_BLOCK) void k_connect_camera(DScene S, RBuf R, Ctl* ctl, float* film, uint32_t* spill4, uint32_t* spill2) {
-    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    __shared__ uint32_t lds_stack[RT_STACK_WORDS];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
-    TravStack st; st.lds = lds_stack + threadIdx.x; st.glob = spill4 ? spill4 + gtid : nullptr; st.gstride = gstride;
+    RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
     const uint32_t n = ctl->n_shadow;
     uint32_t cn = 0, ct = 0, cx = 0;
     const DCamera& cam = S.cam;
@@ -393,9 +513,9 @@ __global__ __launch_bounds__(256) void k_accumulate(RBuf R, float* film, uint32_
 // albedo(), viewNormals(), direct() (Renderer.h:257-296): one ray through the pixel centre (Renderer.h:590).
 __global__ __launch_bounds__(RT_BLOCK) void k_aov(DScene S, RBuf R, Ctl* ctl, int mode, uint64_t seed, uint64_t first_sample, uint32_t n,
                                                   uint32_t* spill4, uint32_t* spill2) {
-    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    __shared__ uint32_t lds_stack[RT_STACK_WORDS];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
-    TravStack st; st.lds = lds_stack + threadIdx.x; st.glob = spill4 ? spill4 + gtid : nullptr; st.gstride = gstride;
+    RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
     uint32_t cn = 0, ct = 0, cx = 0;
     for (;;) {
         unsigned long long base = fetch_chunk(&ctl->work[0]);
@@ -628,9 +748,9 @@ __global__ __launch_bounds__(64) void k_vpl_trace(DScene S, RBuf R, int n_vpl, u
 // computeVPLContribution (Renderer.h:870-907): one lane per shading point, VPLs in slot order; cosine tests run
 // before the shadow ray (same sum, fewer rays than upstream which traces first).
 __global__ __launch_bounds__(RT_BLOCK) void k_gather(DScene S, RBuf R, Ctl* ctl, uint32_t* spill4, uint32_t* spill2) {
-    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    __shared__ uint32_t lds_stack[RT_STACK_WORDS];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
-    TravStack st; st.lds = lds_stack + threadIdx.x; st.glob = spill4 ? spill4 + gtid : nullptr; st.gstride = gstride;
+    RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
     const uint32_t n = ctl->n_gather;
     uint32_t cn = 0, ct = 0, cx = 0;
     unsigned long long nrays = 0;
@@ -786,7 +906,7 @@ extern "C" int rt_renderer_create(rt_scene* scene, rt_renderer** out) {
     if (hipGetDeviceProperties(&prop, scene->device) != hipSuccess) return fail(RT_ERR_DEVICE);
     r->flat_blocks = prop.multiProcessorCount * 8;
     size_t threads = (size_t)r->trav_blocks * RT_BLOCK;
-    if (scene->host.max_stack4 > RT_STACK_LDS && (rc = dev_alloc(r, &r->spill4, threads * (scene->host.max_stack4 - RT_STACK_LDS)))) return fail(rc);
+    if (scene->host.max_stack4 > RT_STACK_LDS && (rc = dev_alloc(r, &r->spill4, threads * (scene->host.max_stack4 - RT_STACK_LDS) * (RT_STACK_KEYS ? 2 : 1)))) return fail(rc);
     if ((rc = dev_alloc(r, &r->spill2, threads * std::max<uint32_t>(scene->host.max_stack2, 2)))) return fail(rc);
     if (hipMemsetAsync(r->ctl, 0, sizeof(Ctl), r->stream) != hipSuccess || hipMemsetAsync(r->counters, 0, sizeof(DCounters), r->stream) != hipSuccess ||
         hipMemsetAsync(r->film_own, 0, sizeof(float) * (size_t)r->W * r->H * 3, r->stream) != hipSuccess)
@@ -833,8 +953,8 @@ static int render_path_like(rt_renderer* r, int mode, uint32_t batch, uint64_t s
         LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n, (uint32_t)r->W * r->H * batch);
         if (r->count_enabled) LAUNCHK(RT_KID_EXTEND, (k_extend<false, true>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
         else LAUNCHK(RT_KID_EXTEND, (k_extend<false, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
-        if (radiosity) LAUNCHK(RT_KID_SHADE, k_shade<true>, r->flat_blocks, 256, S, R, r->ctl, cur, 0);
-        else LAUNCHK(RT_KID_SHADE, k_shade<false>, r->flat_blocks, 256, S, R, r->ctl, cur, 0);
+        if (radiosity) LAUNCHK(RT_KID_SHADE, k_shade<true>, r->flat_blocks / 2, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
+        else LAUNCHK(RT_KID_SHADE, k_shade<false>, r->flat_blocks / 2, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
         if (r->count_enabled) LAUNCHK(RT_KID_CONNECT, k_connect<true>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
         else LAUNCHK(RT_KID_CONNECT, k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
         if (radiosity) LAUNCHK(RT_KID_GATHER, k_gather, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2);

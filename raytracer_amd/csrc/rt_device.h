@@ -10,7 +10,12 @@
 #include "rt_common.h"
 
 #define RT_BLOCK 256
+#ifndef RT_TRAV_WAVES
+#define RT_TRAV_WAVES 6    // __launch_bounds__ waves/SIMD target of the traversal kernels
+#endif
+#ifndef RT_STACK_LDS
 #define RT_STACK_LDS 24          // stack entries per lane kept in LDS (24 KB per 256-thread block)
+#endif
 #define RT_FLT_MAX 3.402823466e+38f
 #define RT_INF __builtin_inff()
 
@@ -69,17 +74,42 @@ __device__ __host__ __forceinline__ float rt_rng_next(Rng& r) {
 
 // ---- traversal stack: the first RT_STACK_LDS entries of each lane live in LDS (lane-interleaved, so a
 // push/pop of the whole wave touches 64 consecutive banks); deeper entries spill to a per-launch HBM array.
+#ifndef RT_STACK_KEYS
+#define RT_STACK_KEYS 0   // measured: the extra LDS plane costs more occupancy than the pop-time cull saves
+#endif
+// An entry is a child reference plus (RT_STACK_KEYS) the padded entry distance of its box, so a subtree that became
+// irrelevant while it waited on the stack is dropped at pop time without fetching its node / triangles.  References
+// and keys live in two lane-interleaved 32-bit planes (LDS: [2][RT_STACK_LDS][RT_BLOCK]).
+#define RT_STACK_WORDS ((RT_STACK_KEYS ? 2 : 1) * RT_STACK_LDS * RT_BLOCK)
 struct TravStack {
     uint32_t* lds;     // &lds_stack[threadIdx.x]
     uint32_t* glob;    // &spill[global thread id], may be null when the scene's bound fits LDS
     uint32_t gstride;  // total threads of the launch
-    __device__ __forceinline__ void put(uint32_t sp, uint32_t v) {
-        if (sp < RT_STACK_LDS) lds[sp * RT_BLOCK] = v; else glob[(size_t)(sp - RT_STACK_LDS) * gstride] = v;
+    uint32_t gkeys;    // offset (in words) of the key plane inside the spill array
+    __device__ __forceinline__ void put(uint32_t sp, uint32_t v, float key) {
+        if (sp < RT_STACK_LDS) {
+            lds[sp * RT_BLOCK] = v;
+            if (RT_STACK_KEYS) lds[(RT_STACK_LDS + sp) * RT_BLOCK] = __float_as_uint(key);
+        } else {
+            size_t o = (size_t)(sp - RT_STACK_LDS) * gstride;
+            glob[o] = v;
+            if (RT_STACK_KEYS) glob[o + gkeys] = __float_as_uint(key);
+        }
     }
-    __device__ __forceinline__ uint32_t get(uint32_t sp) const {
-        return (sp < RT_STACK_LDS) ? lds[sp * RT_BLOCK] : glob[(size_t)(sp - RT_STACK_LDS) * gstride];
+    __device__ __forceinline__ uint32_t get(uint32_t sp, float& key) const {
+        if (sp < RT_STACK_LDS) {
+            key = RT_STACK_KEYS ? __uint_as_float(lds[(RT_STACK_LDS + sp) * RT_BLOCK]) : -RT_INF;
+            return lds[sp * RT_BLOCK];
+        }
+        size_t o = (size_t)(sp - RT_STACK_LDS) * gstride;
+        key = RT_STACK_KEYS ? __uint_as_float(glob[o + gkeys]) : -RT_INF;
+        return glob[o];
     }
 };
+#define RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, max_stack4)                    \
+    TravStack st;                                                                             \
+    st.lds = lds_stack + threadIdx.x; st.glob = spill4 ? spill4 + gtid : nullptr; st.gstride = gstride; \
+    st.gkeys = (max_stack4 > RT_STACK_LDS ? (max_stack4 - RT_STACK_LDS) : 0u) * gstride;
 
 struct HitRec { float t, u, v; uint32_t rank; };
 
@@ -163,11 +193,84 @@ __device__ bool rt_walk_reference(const DScene& S, f3 o, f3 dir, float maxT, Hit
     }
 
 // ---- 4-wide ordered walk.  Closest hit: children sorted near-to-far, subtrees skipped when their box,
+// padded by `padt` (a spatial slack of ~1000 ulp of the largest coordinate, expressed in t), cannot hold a hit
+// in [0, best.t].  Skipping only uses the padded interval; whether a child is *entered* is always the
+// reference's own test on the reference's own box.  Any hit: the reference's box rule
+// (tentry <= texit && !(tentry > maxT)) plus the same padded "entirely behind the origin" skip, any order.
+// Shape: while-while -- every lane descends inner nodes until it holds a leaf (or is done), then the wave
+// tests triangles together, so the expensive leaf code runs with as many lanes as possible.
+template <bool ANY, bool COUNT>
+__device__ bool rt_walk_wide(const DScene& S, f3 o, f3 dir, f3 inv, float maxT, HitRec& best, TravStack& st,
+                             uint32_t& c_nodes, uint32_t& c_tris) {
+    float scale = fmaxf(S.abs_max, fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))));
+    float delta = scale * 6.103515625e-05f;  // 2^-14
+    float padt = delta * fmaxf(fabsf(inv.x), fmaxf(fabsf(inv.y), fabsf(inv.z)));
+    uint32_t sp = 0;
+    uint32_t cur = S.root_ref;  // RT_REF_EMPTY doubles as "done": it has the leaf bit set, so it leaves the inner loop
+    for (;;) {
+        while (!(cur & RT_REF_LEAF)) {
+            const float4* q = reinterpret_cast<const float4*>(S.nodes4 + cur);
+            float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
+            uint4 ch = *reinterpret_cast<const uint4*>(q + 6);
+            if (COUNT) c_nodes++;
+            float k0, k1, k2, k3;
+#define RT_SLOT(LX, LY, LZ, HX, HY, HZ, CH, KEY)                                                         \
+    {                                                                                                      \
+        float ax = (LX - o.x) * inv.x, bx = (HX - o.x) * inv.x;                                            \
+        float ay = (LY - o.y) * inv.y, by = (HY - o.y) * inv.y;                                            \
+        float az = (LZ - o.z) * inv.z, bz = (HZ - o.z) * inv.z;                                            \
+        float tentry = fmaxf(fminf(ax, bx), fmaxf(fminf(ay, by), fminf(az, bz)));                          \
+        float texit = fminf(fmaxf(ax, bx), fminf(fmaxf(ay, by), fmaxf(az, bz)));                           \
+        bool pass = (tentry <= texit) && (CH != RT_REF_EMPTY) && !((texit + padt) < 0.0f);                 \
+        if (ANY) pass = pass && !(tentry > maxT);                                                          \
+        else pass = pass && !((tentry - padt) > best.t);                                                   \
+        KEY = pass ? tentry : RT_INF;                                                                      \
+    }
+            RT_SLOT(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ch.x, k0)
+            RT_SLOT(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ch.y, k1)
+            RT_SLOT(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ch.z, k2)
+            RT_SLOT(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ch.w, k3)
+#undef RT_SLOT
+            uint32_t r0 = ch.x, r1 = ch.y, r2 = ch.z, r3 = ch.w;
+            if (!ANY) { RT_CSWAP(k0, r0, k1, r1) RT_CSWAP(k2, r2, k3, r3) RT_CSWAP(k0, r0, k2, r2) RT_CSWAP(k1, r1, k3, r3) RT_CSWAP(k1, r1, k2, r2) }
+            if (ANY) {  // no order needed: compact the passing children to the front
+                if (!(k2 < RT_INF)) { k2 = k3; r2 = r3; k3 = RT_INF; }
+                if (!(k1 < RT_INF)) { k1 = k2; r1 = r2; k2 = k3; r2 = r3; k3 = RT_INF; }
+                if (!(k0 < RT_INF)) { k0 = k1; r0 = r1; k1 = k2; r1 = r2; k2 = k3; r2 = r3; k3 = RT_INF; }
+            }
+            if (k3 < RT_INF) st.put(sp++, r3, k3 - padt);
+            if (k2 < RT_INF) st.put(sp++, r2, k2 - padt);
+            if (k1 < RT_INF) st.put(sp++, r1, k1 - padt);
+            if (k0 < RT_INF) cur = r0;
+            else {
+                cur = RT_REF_EMPTY;
+                while (sp) { float key; uint32_t c = st.get(--sp, key); if (ANY || !(key > best.t)) { cur = c; break; } }
+            }
+        }
+        if (cur == RT_REF_EMPTY) break;
+        uint32_t first = cur & RT_LEAF_FIRST_MASK, cnt = ((cur >> 27) & 15u) + 1u;
+        for (uint32_t k = 0; k < cnt; k++) {
+            float t, u, v;
+            if (COUNT) c_tris++;
+            if (rt_tri_test(S.tris + first + k, o, dir, t, u, v)) {
+                if (ANY) { if (t < maxT) return false; }
+                else if (t < best.t || (t == best.t && (first + k) < best.rank)) {
+                    best.t = t; best.u = u; best.v = v; best.rank = first + k;
+                }
+            }
+        }
+        cur = RT_REF_EMPTY;
+        while (sp) { float key; uint32_t c = st.get(--sp, key); if (ANY || !(key > best.t)) { cur = c; break; } }
+    }
+    return true;
+}
+
+// ---- 4-wide ordered walk.  Closest hit: children sorted near-to-far, subtrees skipped when their box,
 // padded by `pad` (a spatial slack expressed in t per axis), cannot hold a hit in [0, best.t].  Skipping only
 // uses the padded interval; whether a child is *entered* is always the reference's own test on the
 // reference's own box.  Any hit: the reference's box rule (tentry <= texit && !(tentry > maxT)), any order.
 template <bool ANY, bool COUNT>
-__device__ bool rt_walk_wide(const DScene& S, f3 o, f3 dir, f3 inv, float maxT, HitRec& best, TravStack& st,
+__device__ bool rt_walk_wide_v1(const DScene& S, f3 o, f3 dir, f3 inv, float maxT, HitRec& best, TravStack& st,
                              uint32_t& c_nodes, uint32_t& c_tris) {
     float scale = fmaxf(S.abs_max, fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))));
     float delta = scale * 6.103515625e-05f;  // 2^-14: ~1000 ulp of the largest coordinate in play
@@ -197,7 +300,7 @@ __device__ bool rt_walk_wide(const DScene& S, f3 o, f3 dir, f3 inv, float maxT, 
             float hi_ = fminf(exx + pad.x, fminf(exy + pad.y, exz + pad.z));                               \
             pass = pass && !(lo_ > best.t) && !(hi_ < 0.0f);                                               \
         }                                                                                                  \
-        KEY = pass ? tentry : RT_INF;                                                                      \
+        KEY = pass ? (ANY ? tentry : fmaxf(enx - pad.x, fmaxf(eny - pad.y, enz - pad.z))) : RT_INF;        \
     }
             RT_SLOT(0, lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ch.x, k0)
             RT_SLOT(1, lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ch.y, k1)
@@ -207,14 +310,14 @@ __device__ bool rt_walk_wide(const DScene& S, f3 o, f3 dir, f3 inv, float maxT, 
             uint32_t r0 = ch.x, r1 = ch.y, r2 = ch.z, r3 = ch.w;
             if (!ANY) {
                 RT_CSWAP(k0, r0, k1, r1) RT_CSWAP(k2, r2, k3, r3) RT_CSWAP(k0, r0, k2, r2) RT_CSWAP(k1, r1, k3, r3) RT_CSWAP(k1, r1, k2, r2)
-                if (k3 < RT_INF) st.put(sp++, r3);
-                if (k2 < RT_INF) st.put(sp++, r2);
-                if (k1 < RT_INF) st.put(sp++, r1);
+                if (k3 < RT_INF) st.put(sp++, r3, k3);
+                if (k2 < RT_INF) st.put(sp++, r2, k2);
+                if (k1 < RT_INF) st.put(sp++, r1, k1);
                 if (k0 < RT_INF) { cur = r0; continue; }
             } else {
-                if (k3 < RT_INF) st.put(sp++, r3);
-                if (k2 < RT_INF) st.put(sp++, r2);
-                if (k1 < RT_INF) st.put(sp++, r1);
+                if (k3 < RT_INF) st.put(sp++, r3, k3);
+                if (k2 < RT_INF) st.put(sp++, r2, k2);
+                if (k1 < RT_INF) st.put(sp++, r1, k1);
                 if (k0 < RT_INF) { cur = r0; continue; }
             }
         } else {
@@ -230,8 +333,10 @@ __device__ bool rt_walk_wide(const DScene& S, f3 o, f3 dir, f3 inv, float maxT, 
                 }
             }
         }
-        if (sp == 0) break;
-        cur = st.get(--sp);
+        // pop, dropping entries whose (padded) entry distance now lies beyond the best hit
+        bool got = false;
+        while (sp) { float key; uint32_t c = st.get(--sp, key); if (ANY || !(key > best.t)) { cur = c; got = true; break; } }
+        if (!got) break;
     }
     return true;
 }
@@ -247,7 +352,9 @@ __device__ __forceinline__ void rt_closest(const DScene& S, f3 o, f3 dir, int mo
     // boxes the reference would have walked through on the way.
     if (mode == 0 && dir.x == 0.0f && dir.y == 0.0f && dir.z == 0.0f) return;
     f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-    if (mode == 0 && rt_ray_is_tame(inv)) rt_walk_wide<false, COUNT>(S, o, dir, inv, 0.0f, best, st, cn, ct);
+    if (mode == 0 && rt_ray_is_tame(inv)) {
+        rt_walk_wide_v1<false, COUNT>(S, o, dir, inv, 0.0f, best, st, cn, ct);
+    }
     else { if (COUNT) cexact++; rt_walk_reference<false, COUNT>(S, o, dir, 0.0f, best, spill2, gstride, cn, ct); }
 }
 

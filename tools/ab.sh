@@ -1,0 +1,10 @@
+#!/bin/bash
+# A/B harness: runs bench.py once per library build given on the command line (RT_LIB=<path>)
+for lib in "$@"; do
+  RT_LIB=$PWD/$lib timeout -k 10 300 python -u bench.py --no-cpu-baseline > /tmp/ab.json 2>/tmp/ab.err || { tail -3 /tmp/ab.err; continue; }
+  python - "$lib" <<'PY'
+import json,sys
+d=json.load(open('/tmp/ab.json'))
+print(sys.argv[1], 'Mrays/s %.1f ms/spp %.2f'%(d['value'], d['ms_per_step']), {k:round(v,1) for k,v in d['kernel_ms'].items() if v>1})
+PY
+done
