@@ -165,12 +165,14 @@ def main():
                 "bytes_per_ray": bytes_per_ray,
                 "nodes_per_ray": nodes_per_ray,
                 "tris_per_ray": tris_per_ray,
+                "lane_occupancy": c2["lane_busy"] / max(c2["lane_slots"], 1),
                 "launches": ext_n,
                 "avg_launch_ms": ext_ms / max(ext_n, 1),
                 "note": "algorithmic bytes (every node/triangle fetch counted, cache hits included) / HIP-event time of k_extend",
             },
             "kernel_ms": {k: v[0] for k, v in prof.items()},
             "connect": {"nodes_per_ray": any_nodes_per_ray, "tris_per_ray": any_tris_per_ray,
+                        "lane_occupancy": c2["any_lane_busy"] / max(c2["any_lane_slots"], 1),
                         "rays": cnt["any_rays"], "ms": con_ms, "launches": con_n},
         }
         if not a.no_cpu_baseline and world == 1:

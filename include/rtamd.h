@@ -93,6 +93,8 @@ typedef struct {
     uint64_t nodes_visited, tris_tested;    /* closest-hit walks: wide-node fetches (128 B each) and triangle-record fetches (64 B each) */
     uint64_t exact_path_rays;               /* rays routed through the reference-order fallback walk */
     uint64_t any_nodes_visited, any_tris_tested;  /* the same two counts for any-hit (Scene::visible) walks */
+    uint64_t lane_slots, lane_busy;         /* closest-hit walks: 64 x wave traversal steps, and how many of those lanes held a ray */
+    uint64_t any_lane_slots, any_lane_busy; /* the same for any-hit walks (SIMD lane occupancy = busy / slots) */
 } rt_counters;
 
 typedef struct rt_scene rt_scene;

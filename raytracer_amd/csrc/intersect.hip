@@ -29,67 +29,87 @@ extern "C" int rt_device_set(int device) {
 }
 
 // ------------------------------------------------------------------------------------------------ kernels
-__device__ __forceinline__ unsigned long long rt_fetch_chunk(unsigned long long* work) {
-    unsigned long long base = 0;
-    if ((threadIdx.x & 63) == 0) base = atomicAdd(work, 64ULL);
-    // broadcast lane 0's value to the wave
-    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
-    unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
+// Work source of the batch kernels: one counter, RT_GRANT consecutive items per atomic.
+#define RT_GRANT 256u
+struct CounterSource {
+    unsigned long long* work;
+    uint32_t n;
+    __device__ __forceinline__ bool next(uint32_t& begin, uint32_t& end) {
+        unsigned long long base = 0;
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(work, (unsigned long long)RT_GRANT);
+        unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
+        unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+        if (hi != 0 || lo >= n) return false;
+        begin = lo;
+        end = (n - lo) < RT_GRANT ? n : lo + RT_GRANT;
+        return true;
+    }
+};
 
+struct ClosestJob {
+    const DScene& S;
+    const float* __restrict__ rays;
+    rt_hit* __restrict__ out;
+    uint32_t done;
+    __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d) {
+        const float* r = rays + (size_t)i * 6;
+        o = mk3(r[0], r[1], r[2]); d = mk3(r[3], r[4], r[5]);
+        return true;
+    }
+    __device__ __forceinline__ void retire(uint32_t i, const Walk& w, bool) {
+        const HitRec& h = w.best;
+        rt_hit res;
+        if (h.t < RT_FLT_MAX) {
+            res.ID = S.tris[h.rank].orig_id; res.t = h.t; res.alpha = h.u; res.beta = h.v; res.gamma = 1.0f - (h.u + h.v);  // Geometry.h:450-454
+        } else { res.ID = 0xFFFFFFFFu; res.t = RT_FLT_MAX; res.alpha = res.beta = res.gamma = 0.0f; }
+        out[i] = res;
+        done++;
+    }
+};
+struct AnyJob {
+    const float* __restrict__ segs;
+    uint8_t* __restrict__ out;
+    uint32_t done;
+    __device__ __forceinline__ bool load(uint32_t i, f3& p1, f3& p2) {
+        const float* q = segs + (size_t)i * 6;
+        p1 = mk3(q[0], q[1], q[2]); p2 = mk3(q[3], q[4], q[5]);
+        return true;
+    }
+    __device__ __forceinline__ void retire(uint32_t i, const Walk&, bool visible) { out[i] = visible ? 1 : 0; done++; }
+};
+
+// n <= RT_LAUNCH_MAX items per launch (the host cuts longer batches), so item indices fit 32 bits
+#define RT_LAUNCH_MAX (1u << 30)
 template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_intersect_closest(DScene S, const float* __restrict__ rays, unsigned long long n,
+__global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_intersect_closest(DScene S, const float* __restrict__ rays, uint32_t n,
                                                                 rt_hit* __restrict__ out, int mode, unsigned long long* work,
                                                                 uint32_t* spill4, uint32_t* spill2, DCounters* counters) {
     __shared__ uint32_t lds_stack[RT_STACK_WORDS];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
     RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
-    uint32_t cn = 0, ct = 0, cx = 0, cr = 0;
-    for (;;) {
-        unsigned long long base = rt_fetch_chunk(work);
-        if (base >= n) break;
-        unsigned long long i = base + (threadIdx.x & 63);
-        if (i < n) {
-            const float* r = rays + i * 6;
-            f3 o = mk3(r[0], r[1], r[2]), d = mk3(r[3], r[4], r[5]);
-            HitRec h;
-            rt_closest<COUNT>(S, o, d, mode, h, st, spill2 + gtid, gstride, cn, ct, cx);
-            rt_hit res;
-            if (h.t < RT_FLT_MAX) {
-                res.ID = S.tris[h.rank].orig_id; res.t = h.t; res.alpha = h.u; res.beta = h.v; res.gamma = 1.0f - (h.u + h.v);  // Geometry.h:450-454
-            } else { res.ID = 0xFFFFFFFFu; res.t = RT_FLT_MAX; res.alpha = res.beta = res.gamma = 0.0f; }
-            out[i] = res;
-            if (COUNT) cr++;
-        }
-    }
+    uint32_t cn = 0, ct = 0, cx = 0;
+    ClosestJob job{S, rays, out, 0u};
+    CounterSource src{work, n};
+    rt_persistent_walk<false, COUNT>(S, job, src, mode, st, spill2 + gtid, gstride, cn, ct, cx, counters);
     if (COUNT) {
-        atomicAdd(&counters->closest, (unsigned long long)cr); atomicAdd(&counters->nodes, (unsigned long long)cn);
+        atomicAdd(&counters->closest, (unsigned long long)job.done); atomicAdd(&counters->nodes, (unsigned long long)cn);
         atomicAdd(&counters->tris, (unsigned long long)ct); atomicAdd(&counters->exact, (unsigned long long)cx);
     }
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_intersect_any(DScene S, const float* __restrict__ segs, unsigned long long n,
+__global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_intersect_any(DScene S, const float* __restrict__ segs, uint32_t n,
                                                             uint8_t* __restrict__ out, int mode, unsigned long long* work,
                                                             uint32_t* spill4, uint32_t* spill2, DCounters* counters) {
     __shared__ uint32_t lds_stack[RT_STACK_WORDS];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
     RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
-    uint32_t cn = 0, ct = 0, cx = 0, cr = 0;
-    for (;;) {
-        unsigned long long base = rt_fetch_chunk(work);
-        if (base >= n) break;
-        unsigned long long i = base + (threadIdx.x & 63);
-        if (i < n) {
-            const float* q = segs + i * 6;
-            bool vis = rt_visible<COUNT>(S, mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), mode, st, spill2 + gtid, gstride, cn, ct, cx);
-            out[i] = vis ? 1 : 0;
-            if (COUNT) cr++;
-        }
-    }
+    uint32_t cn = 0, ct = 0, cx = 0;
+    AnyJob job{segs, out, 0u};
+    CounterSource src{work, n};
+    rt_persistent_walk<true, COUNT>(S, job, src, mode, st, spill2 + gtid, gstride, cn, ct, cx, counters);
     if (COUNT) {
-        atomicAdd(&counters->any, (unsigned long long)cr); atomicAdd(&counters->any_nodes, (unsigned long long)cn);
+        atomicAdd(&counters->any, (unsigned long long)job.done); atomicAdd(&counters->any_nodes, (unsigned long long)cn);
         atomicAdd(&counters->any_tris, (unsigned long long)ct); atomicAdd(&counters->exact, (unsigned long long)cx);
     }
 }
@@ -246,6 +266,7 @@ extern "C" int rt_counters_read(rt_scene* s, rt_counters* o, int reset) {
     RT_HIP(hipMemcpy(&c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     o->closest_rays = c.closest; o->any_rays = c.any; o->nodes_visited = c.nodes; o->tris_tested = c.tris; o->exact_path_rays = c.exact;
     o->any_nodes_visited = c.any_nodes; o->any_tris_tested = c.any_tris;
+    o->lane_slots = c.slots; o->lane_busy = c.busy; o->any_lane_slots = c.any_slots; o->any_lane_busy = c.any_busy;
     if (reset) RT_HIP(hipMemset(s->d_counters, 0, sizeof(DCounters)));
     return RT_OK;
 }
@@ -263,15 +284,19 @@ extern "C" int rt_intersect_closest_dev(rt_scene* s, const rt_ray* d_rays, size_
     if (n == 0) return RT_OK;
     hipStream_t st = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(s->mu);  // the work counter and the stack spill are per scene
-    RT_HIP(hipMemsetAsync(s->d_work, 0, sizeof(unsigned long long), st));
-    int blocks = (int)std::min<size_t>((n + RT_BLOCK - 1) / RT_BLOCK, (size_t)s->persistent_blocks);
-    if (s->count_enabled)
-        hipLaunchKernelGGL(k_intersect_closest<true>, dim3(blocks), dim3(RT_BLOCK), 0, st, s->d, (const float*)d_rays, (unsigned long long)n, d_out,
-                           mode, s->d_work, s->d_spill4, s->d_spill2, s->d_counters);
-    else
-        hipLaunchKernelGGL(k_intersect_closest<false>, dim3(blocks), dim3(RT_BLOCK), 0, st, s->d, (const float*)d_rays, (unsigned long long)n, d_out,
-                           mode, s->d_work, s->d_spill4, s->d_spill2, s->d_counters);
-    RT_HIP(hipGetLastError());
+    for (size_t off = 0; off < n; off += RT_LAUNCH_MAX) {
+        const uint32_t m = (uint32_t)std::min<size_t>(n - off, RT_LAUNCH_MAX);
+        const float* in = (const float*)(d_rays + off);
+        RT_HIP(hipMemsetAsync(s->d_work, 0, sizeof(unsigned long long), st));
+        int blocks = (int)std::min<size_t>(((size_t)m + RT_BLOCK - 1) / RT_BLOCK, (size_t)s->persistent_blocks);
+        if (s->count_enabled)
+            hipLaunchKernelGGL(k_intersect_closest<true>, dim3(blocks), dim3(RT_BLOCK), 0, st, s->d, in, m, d_out + off, mode, s->d_work,
+                               s->d_spill4, s->d_spill2, s->d_counters);
+        else
+            hipLaunchKernelGGL(k_intersect_closest<false>, dim3(blocks), dim3(RT_BLOCK), 0, st, s->d, in, m, d_out + off, mode, s->d_work,
+                               s->d_spill4, s->d_spill2, s->d_counters);
+        RT_HIP(hipGetLastError());
+    }
     return RT_OK;
 }
 
@@ -281,15 +306,19 @@ extern "C" int rt_intersect_any_dev(rt_scene* s, const rt_segment* d_segs, size_
     if (n == 0) return RT_OK;
     hipStream_t st = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(s->mu);
-    RT_HIP(hipMemsetAsync(s->d_work, 0, sizeof(unsigned long long), st));
-    int blocks = (int)std::min<size_t>((n + RT_BLOCK - 1) / RT_BLOCK, (size_t)s->persistent_blocks);
-    if (s->count_enabled)
-        hipLaunchKernelGGL(k_intersect_any<true>, dim3(blocks), dim3(RT_BLOCK), 0, st, s->d, (const float*)d_segs, (unsigned long long)n, d_out, mode,
-                           s->d_work, s->d_spill4, s->d_spill2, s->d_counters);
-    else
-        hipLaunchKernelGGL(k_intersect_any<false>, dim3(blocks), dim3(RT_BLOCK), 0, st, s->d, (const float*)d_segs, (unsigned long long)n, d_out, mode,
-                           s->d_work, s->d_spill4, s->d_spill2, s->d_counters);
-    RT_HIP(hipGetLastError());
+    for (size_t off = 0; off < n; off += RT_LAUNCH_MAX) {
+        const uint32_t m = (uint32_t)std::min<size_t>(n - off, RT_LAUNCH_MAX);
+        const float* in = (const float*)(d_segs + off);
+        RT_HIP(hipMemsetAsync(s->d_work, 0, sizeof(unsigned long long), st));
+        int blocks = (int)std::min<size_t>(((size_t)m + RT_BLOCK - 1) / RT_BLOCK, (size_t)s->persistent_blocks);
+        if (s->count_enabled)
+            hipLaunchKernelGGL(k_intersect_any<true>, dim3(blocks), dim3(RT_BLOCK), 0, st, s->d, in, m, d_out + off, mode, s->d_work,
+                               s->d_spill4, s->d_spill2, s->d_counters);
+        else
+            hipLaunchKernelGGL(k_intersect_any<false>, dim3(blocks), dim3(RT_BLOCK), 0, st, s->d, in, m, d_out + off, mode, s->d_work,
+                               s->d_spill4, s->d_spill2, s->d_counters);
+        RT_HIP(hipGetLastError());
+    }
     return RT_OK;
 }
 

@@ -35,6 +35,7 @@ struct RBuf {  // device buffers of one renderer
     float4 *ray_o, *ray_d, *hit, *thr, *rad;
     uint32_t* q_active[2];
     uint32_t* q_class;   // RT_NCLASS * cap
+    uint32_t* cls;       // per path: BSDF class of the hit extend found, RT_CLS_NONE when the path ended
     float4* shadow;      // 3 * cap
     float4* gather;      // 4 * cap (radiosity requests)
     float4* vpl;         // 4 * vpl_cap
@@ -212,105 +213,95 @@ __global__ __launch_bounds__(256) void k_generate(DScene S, RBuf R, uint32_t n, 
 // Scene::traverse for every live path + the two trivial outcomes of pathTrace handled in place:
 // escaped rays add background->evaluate(dir) un-weighted (Renderer.h:254) and emitters add T*Le only when
 // canHitLight (Renderer.h:221-231).  Everything else is binned by BSDF class for the shade kernel.
-#ifndef RT_EXTEND_STAGE
-#define RT_EXTEND_STAGE 0   // measured: per-wave LDS staging of the class queues is slower than one atomic per class per chunk
-#endif
-#define RT_STAGE 128   // per-wave, per-class staging slots in LDS (flushed 64 at a time)
+#define RT_CLS_NONE 0xFFu
+struct XcdSource {   // rt_persistent_walk's Source over the XCD-sharded work counters
+    XcdFetch xf;
+    unsigned long long (*w)[16];
+    uint32_t n;
+    __device__ __forceinline__ bool next(uint32_t& begin, uint32_t& end) {
+        uint32_t b, e;
+        if (!xf.next(w, n, b, e)) return false;
+        begin = b;
+        end = (e - b) < 64u * RT_FETCH_CHUNKS ? e : b + 64u * RT_FETCH_CHUNKS;
+        return true;
+    }
+};
+template <bool LT>
+struct ExtendJob {
+    const DScene& S;
+    const RBuf& R;
+    const uint32_t* queue;
+    int first;
+    __device__ __forceinline__ uint32_t path_of(uint32_t i) const { return first ? i : queue[i]; }
+    __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d) {
+        uint32_t path = path_of(i);
+        if (__float_as_uint(R.thr[path].w) & RT_FLAG_DEAD) { R.cls[path] = RT_CLS_NONE; return false; }
+        float4 ro = R.ray_o[path], rd = R.ray_d[path];
+        o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z);
+        return true;
+    }
+    __device__ __forceinline__ void retire(uint32_t i, const Walk& w, bool) {
+        const HitRec& h = w.best;
+        uint32_t path = path_of(i);
+        uint32_t cls = RT_CLS_NONE;
+        if (h.t < RT_FLT_MAX) {
+            uint32_t mat = S.tris[h.rank].mat_gsign & 0x7FFFFFFFu;
+            const DMaterial& m = S.mats[mat];
+            if (!LT && (m.flags & RT_MF_LIGHT)) {
+                float4 th = R.thr[path];
+                if (__float_as_uint(th.w) & RT_FLAG_CANHIT) {
+                    float4 L = R.rad[path];
+                    col3 c = mkc(th.x, th.y, th.z) * mat_emission(m);
+                    R.rad[path] = make_float4(L.x + c.r, L.y + c.g, L.z + c.b, L.w);
+                }
+            } else {
+                R.hit[path] = make_float4(h.t, h.u, h.v, __uint_as_float(h.rank));
+                cls = LT ? 0u : (uint32_t)class_of(m.type);
+            }
+        } else if (!LT) {
+            float4 L = R.rad[path];
+            float4 rd = R.ray_d[path];  // not w.dir: a zero / untamed direction never initialises the walk
+            col3 c = bg_evaluate(S, mk3(rd.x, rd.y, rd.z));
+            R.rad[path] = make_float4(L.x + c.r, L.y + c.g, L.z + c.b, L.w);
+        }
+        R.cls[path] = cls;
+    }
+};
 template <bool LT, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_extend(DScene S, RBuf R, Ctl* ctl, int cur, int first, uint32_t* spill4, uint32_t* spill2,
                                                      DCounters* counters) {
     __shared__ uint32_t lds_stack[RT_STACK_WORDS];
-    // survivors are staged per wave and per BSDF class in LDS and flushed 64 at a time: one queue atomic and one
-    // coalesced 256-B store per 64 paths instead of one atomic per class per 64-ray chunk
-#if RT_EXTEND_STAGE
-    __shared__ uint32_t lds_stage[(RT_BLOCK / 64) * RT_NCLASS * RT_STAGE];
-#else
-    uint32_t* lds_stage = nullptr;
-#endif
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
-    const uint32_t lane = threadIdx.x & 63;
     RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
-    uint32_t* stage = lds_stage + (threadIdx.x >> 6) * (RT_NCLASS * RT_STAGE);
-    constexpr int NC = LT ? 1 : RT_NCLASS;
-    uint32_t staged[NC];
-#pragma unroll
-    for (int c = 0; c < NC; c++) staged[c] = 0;
     const uint32_t n = ctl->n_active[cur];
-    const uint32_t* queue = R.q_active[cur];
     uint32_t cn = 0, ct = 0, cx = 0;
-    XcdFetch xf; xf.init(n);
-    for (;;) {
-        uint32_t base0, end0;
-        if (!xf.next(ctl->work_x[0], n, base0, end0)) break;
-        for (unsigned g = 0; g < RT_FETCH_CHUNKS; g++) {
-            uint32_t base = base0 + 64u * g;
-            if (base >= end0) break;
-            uint32_t i = base + lane;
-            int cls = -1;
-            uint32_t path = 0;
-            if (i < end0) {
-                path = first ? i : queue[i];
-                float4 th = R.thr[path];
-                uint32_t flags = __float_as_uint(th.w);
-                if (!(flags & RT_FLAG_DEAD)) {
-                    float4 ro = R.ray_o[path], rd = R.ray_d[path];
-                    f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
-                    HitRec h;
-                    rt_closest<COUNT>(S, o, d, 0, h, st, spill2 + gtid, gstride, cn, ct, cx);
-                    if (h.t < RT_FLT_MAX) {
-                        uint32_t mat = S.tris[h.rank].mat_gsign & 0x7FFFFFFFu;
-                        const DMaterial& m = S.mats[mat];
-                        if (!LT && (m.flags & RT_MF_LIGHT)) {
-                            if (flags & RT_FLAG_CANHIT) {
-                                float4 L = R.rad[path];
-                                col3 c = mkc(th.x, th.y, th.z) * mat_emission(m);
-                                R.rad[path] = make_float4(L.x + c.r, L.y + c.g, L.z + c.b, L.w);
-                            }
-                        } else {
-                            R.hit[path] = make_float4(h.t, h.u, h.v, __uint_as_float(h.rank));
-                            cls = LT ? 0 : class_of(m.type);
-                        }
-                    } else if (!LT) {
-                        float4 L = R.rad[path];
-                        col3 c = bg_evaluate(S, d);
-                        R.rad[path] = make_float4(L.x + c.r, L.y + c.g, L.z + c.b, L.w);
-                    }
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                bool mine = cls == c;
-#if !RT_EXTEND_STAGE
-                { uint32_t slot = wave_append(&ctl->n_class[c], mine); if (mine) R.q_class[(size_t)c * R.cap + slot] = path; continue; }
-#endif
-                unsigned long long mask = __ballot(mine);
-                if (mask == 0) continue;
-                uint32_t* buf = stage + c * RT_STAGE;
-                if (mine) buf[staged[c] + (uint32_t)__popcll(mask & ((1ULL << lane) - 1ULL))] = path;
-                staged[c] += (uint32_t)__popcll(mask);
-                if (staged[c] >= 64) {  // flush one full wave-width
-                    uint32_t qb = 0;
-                    if (lane == 0) qb = atomicAdd(&ctl->n_class[c], 64u);
-                    qb = __builtin_amdgcn_readfirstlane(qb);
-                    R.q_class[(size_t)c * R.cap + qb + lane] = buf[lane];
-                    uint32_t tail = buf[64 + lane];
-                    buf[lane] = tail;
-                    staged[c] -= 64;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-        if (staged[c] == 0) continue;
-        uint32_t qb = 0;
-        if (lane == 0) qb = atomicAdd(&ctl->n_class[c], staged[c]);
-        qb = __builtin_amdgcn_readfirstlane(qb);
-        if (lane < staged[c]) R.q_class[(size_t)c * R.cap + qb + lane] = stage[c * RT_STAGE + lane];
-    }
+    ExtendJob<LT> job{S, R, R.q_active[cur], first};
+    XcdSource src; src.xf.init(n); src.w = ctl->work_x[0]; src.n = n;
+    rt_persistent_walk<false, COUNT>(S, job, src, 0, st, spill2 + gtid, gstride, cn, ct, cx, counters);
     if (COUNT) {
         atomicAdd(&counters->nodes, (unsigned long long)cn); atomicAdd(&counters->tris, (unsigned long long)ct);
         atomicAdd(&counters->exact, (unsigned long long)cx);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ bin
+// Material sorting: the hits extend left behind (R.cls per path) are binned into one queue per BSDF class, in
+// queue order, so a shade wave runs one material's code.  Block-lockstep: one atomic per class per 512 paths.
+#define RT_BIN_BLOCK 512
+__global__ __launch_bounds__(RT_BIN_BLOCK) void k_bin(RBuf R, Ctl* ctl, int cur, int first) {
+    __shared__ uint32_t s_app[RT_NCLASS * (RT_BIN_BLOCK / 64 + 1)];
+    const uint32_t n = ctl->n_active[cur];
+    const uint32_t* queue = R.q_active[cur];
+    for (uint32_t base = blockIdx.x * RT_BIN_BLOCK; base < n; base += gridDim.x * RT_BIN_BLOCK) {
+        uint32_t i = base + threadIdx.x, path = 0, c = RT_CLS_NONE;
+        if (i < n) { path = first ? i : queue[i]; c = R.cls[path]; }
+        uint32_t* const counters[RT_NCLASS] = { &ctl->n_class[0], &ctl->n_class[1], &ctl->n_class[2], &ctl->n_class[3], &ctl->n_class[4], &ctl->n_class[5] };
+        const bool pred[RT_NCLASS] = { c == 0, c == 1, c == 2, c == 3, c == 4, c == 5 };
+        uint32_t slot[RT_NCLASS];
+        block_append<RT_NCLASS, RT_BIN_BLOCK / 64>(counters, pred, slot, s_app);
+#pragma unroll
+        for (int q = 0; q < RT_NCLASS; q++) if (pred[q]) R.q_class[(size_t)q * R.cap + slot[q]] = path;
+        __syncthreads();  // s_app is reused by the next iteration
     }
 }
 
@@ -428,6 +419,23 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene S, RBuf R, Ctl*
 
 // ------------------------------------------------------------------------------------------------ connect
 // Scene::visible for every NEE request; visible ones add their (already throughput-weighted) term.
+struct ConnectJob {
+    const RBuf& R;
+    __device__ __forceinline__ bool load(uint32_t i, f3& p1, f3& p2) {
+        const float4* e = R.shadow + (size_t)i * 3;
+        float4 a = e[0], b = e[1];
+        p1 = mk3(a.x, a.y, a.z); p2 = mk3(b.x, b.y, b.z);
+        return true;
+    }
+    __device__ __forceinline__ void retire(uint32_t i, const Walk&, bool visible) {
+        if (!visible) return;
+        const float4* e = R.shadow + (size_t)i * 3;
+        uint32_t path = __float_as_uint(e[0].w);
+        float4 c = e[2];
+        float4 L = R.rad[path];
+        R.rad[path] = make_float4(L.x + c.x, L.y + c.y, L.z + c.z, L.w);
+    }
+};
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_connect(DScene S, RBuf R, Ctl* ctl, uint32_t* spill4, uint32_t* spill2, DCounters* counters) {
     __shared__ uint32_t lds_stack[RT_STACK_WORDS];
@@ -435,24 +443,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_connect(DScene S, R
     RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
     const uint32_t n = ctl->n_shadow;
     uint32_t cn = 0, ct = 0, cx = 0;
-    XcdFetch xf; xf.init(n);
-    for (;;) {
-        uint32_t base0, end0;
-        if (!xf.next(ctl->work_x[1], n, base0, end0)) break;
-        for (unsigned g = 0; g < RT_FETCH_CHUNKS; g++) {
-        uint32_t i = base0 + 64u * g + (threadIdx.x & 63);
-        if (i < end0) {
-            const float4* e = R.shadow + (size_t)i * 3;
-            float4 a = e[0], b = e[1];
-            if (rt_visible<COUNT>(S, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), 0, st, spill2 + gtid, gstride, cn, ct, cx)) {
-                float4 c = e[2];
-                uint32_t path = __float_as_uint(a.w);
-                float4 L = R.rad[path];
-                R.rad[path] = make_float4(L.x + c.x, L.y + c.y, L.z + c.z, L.w);
-            }
-        }
-        }
-    }
+    ConnectJob job{R};
+    XcdSource src; src.xf.init(n); src.w = ctl->work_x[1]; src.n = n;
+    rt_persistent_walk<true, COUNT>(S, job, src, 0, st, spill2 + gtid, gstride, cn, ct, cx, counters);
     if (COUNT) {
         atomicAdd(&counters->any_nodes, (unsigned long long)cn); atomicAdd(&counters->any_tris, (unsigned long long)ct);
         atomicAdd(&counters->exact, (unsigned long long)cx);
@@ -895,7 +888,7 @@ extern "C" int rt_renderer_create(rt_scene* scene, rt_renderer** out) {
     if (hipStreamCreate(&r->stream) != hipSuccess) { rt_set_error("rt_renderer_create: hipStreamCreate failed"); return fail(RT_ERR_DEVICE); }
     if ((rc = dev_alloc(r, &R.ray_o, R.cap)) || (rc = dev_alloc(r, &R.ray_d, R.cap)) || (rc = dev_alloc(r, &R.hit, R.cap)) ||
         (rc = dev_alloc(r, &R.thr, R.cap)) || (rc = dev_alloc(r, &R.rad, R.cap)) || (rc = dev_alloc(r, &R.q_active[0], R.cap)) ||
-        (rc = dev_alloc(r, &R.q_active[1], R.cap)) || (rc = dev_alloc(r, &R.q_class, (size_t)R.cap * RT_NCLASS)) ||
+        (rc = dev_alloc(r, &R.q_active[1], R.cap)) || (rc = dev_alloc(r, &R.q_class, (size_t)R.cap * RT_NCLASS)) || (rc = dev_alloc(r, &R.cls, R.cap)) ||
         (rc = dev_alloc(r, &R.shadow, (size_t)R.cap * 3)) || (rc = dev_alloc(r, &r->ctl, 1)) || (rc = dev_alloc(r, &r->counters, 1)) ||
         (rc = dev_alloc(r, &r->film_own, (size_t)r->W * r->H * 3)))
         return fail(rc);
@@ -953,6 +946,7 @@ static int render_path_like(rt_renderer* r, int mode, uint32_t batch, uint64_t s
         LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n, (uint32_t)r->W * r->H * batch);
         if (r->count_enabled) LAUNCHK(RT_KID_EXTEND, (k_extend<false, true>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
         else LAUNCHK(RT_KID_EXTEND, (k_extend<false, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
+        LAUNCH(k_bin, r->flat_blocks / 2, RT_BIN_BLOCK, R, r->ctl, cur, b == 0 ? 1 : 0);
         if (radiosity) LAUNCHK(RT_KID_SHADE, k_shade<true>, r->flat_blocks / 2, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
         else LAUNCHK(RT_KID_SHADE, k_shade<false>, r->flat_blocks / 2, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
         if (r->count_enabled) LAUNCHK(RT_KID_CONNECT, k_connect<true>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
@@ -990,6 +984,7 @@ static int render_light(rt_renderer* r, uint32_t batch, uint64_t seed, uint64_t 
         int cur = b & 1;
         LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n, n);
         LAUNCHK(RT_KID_EXTEND, (k_extend<true, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
+        LAUNCH(k_bin, r->flat_blocks / 2, RT_BIN_BLOCK, R, r->ctl, cur, b == 0 ? 1 : 0);
         LAUNCHK(RT_KID_SHADE, k_lt_shade, r->flat_blocks, 256, S, R, r->ctl, cur);
         LAUNCHK(RT_KID_CONNECT, k_connect_camera, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->spill4, r->spill2);
     }
@@ -1078,6 +1073,7 @@ extern "C" int rt_render_counters(rt_renderer* r, rt_counters* o, int reset) {
     RT_HIP(hipMemcpy(&d, r->counters, sizeof(d), hipMemcpyDeviceToHost));
     o->closest_rays = c.tot_closest; o->any_rays = c.tot_any; o->nodes_visited = d.nodes; o->tris_tested = d.tris; o->exact_path_rays = d.exact;
     o->any_nodes_visited = d.any_nodes; o->any_tris_tested = d.any_tris;
+    o->lane_slots = d.slots; o->lane_busy = d.busy; o->any_lane_slots = d.any_slots; o->any_lane_busy = d.any_busy;
     if (reset) {
         RT_HIP(hipMemset(r->ctl, 0, sizeof(Ctl)));
         RT_HIP(hipMemset(r->counters, 0, sizeof(DCounters)));

@@ -114,9 +114,8 @@ struct TravStack {
 struct HitRec { float t, u, v; uint32_t rank; };
 
 // Triangle::rayIntersect (Geometry.h:115-128), same expression tree; inv_area is the hoisted 1/Dot(e1 x e2, n).
-__device__ __forceinline__ bool rt_tri_test(const DTri* __restrict__ tp, f3 o, f3 dir, float& t, float& u, float& v) {
-    const float4* q = reinterpret_cast<const float4*>(tp);
-    float4 a = q[0], b = q[1], c = q[2], e = q[3];
+// a, b, c, e are the four 16-B pieces of a DTri record.
+__device__ __forceinline__ bool rt_tri_eval(float4 a, float4 b, float4 c, float4 e, f3 o, f3 dir, float& t, float& u, float& v) {
     f3 n = mk3(c.y, c.z, c.w);
     float denom = dot3(n, dir);
     if (denom == 0) return false;
@@ -130,6 +129,24 @@ __device__ __forceinline__ bool rt_tri_test(const DTri* __restrict__ tp, f3 o, f
     v = dot3(cross3(e2, p - v2), n) * e.y;
     if (v < 0 || (u + v) > 1.0f) return false;
     return true;
+}
+// The same test with the early returns folded into one predicate (same operations, same NaN behaviour: a
+// comparison with NaN rejects nothing, as upstream): no dependent second round of loads, no divergent branches.
+__device__ __forceinline__ bool rt_tri_eval_all(float4 a, float4 b, float4 c, float4 e, f3 o, f3 dir, float& t, float& u, float& v) {
+    f3 n = mk3(c.y, c.z, c.w);
+    float denom = dot3(n, dir);
+    t = (e.x - dot3(n, o)) / denom;
+    f3 v0 = mk3(a.x, a.y, a.z), v1 = mk3(a.w, b.x, b.y), v2 = mk3(b.z, b.w, c.x);
+    f3 p = o + (dir * t);
+    f3 e1 = v2 - v1, e2 = v0 - v2;
+    u = dot3(cross3(e1, p - v1), n) * e.y;
+    v = dot3(cross3(e2, p - v2), n) * e.y;
+    bool reject = (denom == 0) | (t < 0) | (u < 0) | (u > 1.0f) | (v < 0) | ((u + v) > 1.0f);
+    return !reject;
+}
+__device__ __forceinline__ bool rt_tri_test(const DTri* __restrict__ tp, f3 o, f3 dir, float& t, float& u, float& v) {
+    const float4* q = reinterpret_cast<const float4*>(tp);
+    return rt_tri_eval(q[0], q[1], q[2], q[3], o, dir, t, u, v);
 }
 
 // AABB::rayAABB (Geometry.h:207-229) verbatim, ternary Min/Max + std::max/min: used by the reference-order walk.
@@ -192,99 +209,37 @@ __device__ bool rt_walk_reference(const DScene& S, f3 o, f3 dir, float maxT, Hit
         uint32_t tr_ = s_ ? rb : ra; rb = s_ ? ra : rb; ra = tr_; \
     }
 
-// ---- 4-wide ordered walk.  Closest hit: children sorted near-to-far, subtrees skipped when their box,
-// padded by `padt` (a spatial slack of ~1000 ulp of the largest coordinate, expressed in t), cannot hold a hit
-// in [0, best.t].  Skipping only uses the padded interval; whether a child is *entered* is always the
-// reference's own test on the reference's own box.  Any hit: the reference's box rule
-// (tentry <= texit && !(tentry > maxT)) plus the same padded "entirely behind the origin" skip, any order.
-// Shape: while-while -- every lane descends inner nodes until it holds a leaf (or is done), then the wave
-// tests triangles together, so the expensive leaf code runs with as many lanes as possible.
-template <bool ANY, bool COUNT>
-__device__ bool rt_walk_wide(const DScene& S, f3 o, f3 dir, f3 inv, float maxT, HitRec& best, TravStack& st,
-                             uint32_t& c_nodes, uint32_t& c_tris) {
-    float scale = fmaxf(S.abs_max, fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))));
-    float delta = scale * 6.103515625e-05f;  // 2^-14
-    float padt = delta * fmaxf(fabsf(inv.x), fmaxf(fabsf(inv.y), fabsf(inv.z)));
-    uint32_t sp = 0;
-    uint32_t cur = S.root_ref;  // RT_REF_EMPTY doubles as "done": it has the leaf bit set, so it leaves the inner loop
-    for (;;) {
-        while (!(cur & RT_REF_LEAF)) {
-            const float4* q = reinterpret_cast<const float4*>(S.nodes4 + cur);
-            float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
-            uint4 ch = *reinterpret_cast<const uint4*>(q + 6);
-            if (COUNT) c_nodes++;
-            float k0, k1, k2, k3;
-#define RT_SLOT(LX, LY, LZ, HX, HY, HZ, CH, KEY)                                                         \
-    {                                                                                                      \
-        float ax = (LX - o.x) * inv.x, bx = (HX - o.x) * inv.x;                                            \
-        float ay = (LY - o.y) * inv.y, by = (HY - o.y) * inv.y;                                            \
-        float az = (LZ - o.z) * inv.z, bz = (HZ - o.z) * inv.z;                                            \
-        float tentry = fmaxf(fminf(ax, bx), fmaxf(fminf(ay, by), fminf(az, bz)));                          \
-        float texit = fminf(fmaxf(ax, bx), fminf(fmaxf(ay, by), fmaxf(az, bz)));                           \
-        bool pass = (tentry <= texit) && (CH != RT_REF_EMPTY) && !((texit + padt) < 0.0f);                 \
-        if (ANY) pass = pass && !(tentry > maxT);                                                          \
-        else pass = pass && !((tentry - padt) > best.t);                                                   \
-        KEY = pass ? tentry : RT_INF;                                                                      \
-    }
-            RT_SLOT(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ch.x, k0)
-            RT_SLOT(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ch.y, k1)
-            RT_SLOT(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ch.z, k2)
-            RT_SLOT(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ch.w, k3)
-#undef RT_SLOT
-            uint32_t r0 = ch.x, r1 = ch.y, r2 = ch.z, r3 = ch.w;
-            if (!ANY) { RT_CSWAP(k0, r0, k1, r1) RT_CSWAP(k2, r2, k3, r3) RT_CSWAP(k0, r0, k2, r2) RT_CSWAP(k1, r1, k3, r3) RT_CSWAP(k1, r1, k2, r2) }
-            if (ANY) {  // no order needed: compact the passing children to the front
-                if (!(k2 < RT_INF)) { k2 = k3; r2 = r3; k3 = RT_INF; }
-                if (!(k1 < RT_INF)) { k1 = k2; r1 = r2; k2 = k3; r2 = r3; k3 = RT_INF; }
-                if (!(k0 < RT_INF)) { k0 = k1; r0 = r1; k1 = k2; r1 = r2; k2 = k3; r2 = r3; k3 = RT_INF; }
-            }
-            if (k3 < RT_INF) st.put(sp++, r3, k3 - padt);
-            if (k2 < RT_INF) st.put(sp++, r2, k2 - padt);
-            if (k1 < RT_INF) st.put(sp++, r1, k1 - padt);
-            if (k0 < RT_INF) cur = r0;
-            else {
-                cur = RT_REF_EMPTY;
-                while (sp) { float key; uint32_t c = st.get(--sp, key); if (ANY || !(key > best.t)) { cur = c; break; } }
-            }
-        }
-        if (cur == RT_REF_EMPTY) break;
-        uint32_t first = cur & RT_LEAF_FIRST_MASK, cnt = ((cur >> 27) & 15u) + 1u;
-        for (uint32_t k = 0; k < cnt; k++) {
-            float t, u, v;
-            if (COUNT) c_tris++;
-            if (rt_tri_test(S.tris + first + k, o, dir, t, u, v)) {
-                if (ANY) { if (t < maxT) return false; }
-                else if (t < best.t || (t == best.t && (first + k) < best.rank)) {
-                    best.t = t; best.u = u; best.v = v; best.rank = first + k;
-                }
-            }
-        }
-        cur = RT_REF_EMPTY;
-        while (sp) { float key; uint32_t c = st.get(--sp, key); if (ANY || !(key > best.t)) { cur = c; break; } }
-    }
-    return true;
-}
-
-// ---- 4-wide ordered walk.  Closest hit: children sorted near-to-far, subtrees skipped when their box,
-// padded by `pad` (a spatial slack expressed in t per axis), cannot hold a hit in [0, best.t].  Skipping only
-// uses the padded interval; whether a child is *entered* is always the reference's own test on the
-// reference's own box.  Any hit: the reference's box rule (tentry <= texit && !(tentry > maxT)), any order.
-template <bool ANY, bool COUNT>
-__device__ bool rt_walk_wide_v1(const DScene& S, f3 o, f3 dir, f3 inv, float maxT, HitRec& best, TravStack& st,
-                             uint32_t& c_nodes, uint32_t& c_tris) {
+// ---- 4-wide ordered walk, one step at a time.  The per-lane state lives in a Walk so that a wave can keep
+// stepping the rays it has while lanes whose ray finished are handed new ones (rt_persistent_walk below).
+//
+// Closest hit: children sorted near-to-far, subtrees skipped when their box, padded by `pad` (a spatial slack of
+// ~1000 ulp of the largest coordinate, expressed in t per axis), cannot hold a hit in [0, best.t].  Any hit: the
+// reference's box rule (tentry <= texit && !(tentry > maxT)) plus a padded "entirely behind the origin" skip, any
+// order.  Skipping only uses the padded interval; whether a child is *entered* is always the reference's own
+// test on the reference's own box.
+struct Walk {
+    f3 o, dir, inv;
+    f3 pad;        // closest hit
+    float maxT, padt;  // any hit
+    HitRec best;
+    uint32_t cur, sp;
+    bool occluded;
+};
+__device__ __forceinline__ void rt_walk_init(const DScene& S, Walk& w, f3 o, f3 dir, f3 inv, float maxT) {
     float scale = fmaxf(S.abs_max, fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))));
     float delta = scale * 6.103515625e-05f;  // 2^-14: ~1000 ulp of the largest coordinate in play
-    f3 pad = mk3(delta * fabsf(inv.x), delta * fabsf(inv.y), delta * fabsf(inv.z));
-    uint32_t sp = 0;
-    uint32_t cur = S.root_ref;
-    while (true) {
-        if (!(cur & RT_REF_LEAF)) {
-            const float4* q = reinterpret_cast<const float4*>(S.nodes4 + cur);
-            float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
-            uint4 ch = *reinterpret_cast<const uint4*>(q + 6);
-            if (COUNT) c_nodes++;
-            float k0, k1, k2, k3;
-#define RT_SLOT(i, LX, LY, LZ, HX, HY, HZ, CH, KEY)                                                      \
+    w.o = o; w.dir = dir; w.inv = inv;
+    w.pad = mk3(delta * fabsf(inv.x), delta * fabsf(inv.y), delta * fabsf(inv.z));
+    w.padt = delta * fmaxf(fabsf(inv.x), fmaxf(fabsf(inv.y), fabsf(inv.z)));
+    w.maxT = maxT;
+    w.cur = S.root_ref; w.sp = 0; w.occluded = false;
+}
+// Box tests of one 4-wide node: pushes the passing children but the nearest, which becomes w.cur (returns true).
+template <bool ANY>
+__device__ __forceinline__ bool rt_node_eval(Walk& w, TravStack& st, float4 lox, float4 loy, float4 loz, float4 hix, float4 hiy, float4 hiz, uint4 ch) {
+    const f3 o = w.o, inv = w.inv;
+    float k0, k1, k2, k3;
+#define RT_SLOT(LX, LY, LZ, HX, HY, HZ, CH, KEY)                                                         \
     {                                                                                                      \
         float ax = (LX - o.x) * inv.x, bx = (HX - o.x) * inv.x;                                            \
         float ay = (LY - o.y) * inv.y, by = (HY - o.y) * inv.y;                                            \
@@ -294,82 +249,227 @@ __device__ bool rt_walk_wide_v1(const DScene& S, f3 o, f3 dir, f3 inv, float max
         float tentry = fmaxf(enx, fmaxf(eny, enz));                                                        \
         float texit = fminf(exx, fminf(exy, exz));                                                         \
         bool pass = (tentry <= texit) && (CH != RT_REF_EMPTY);                                             \
-        if (ANY) pass = pass && !(tentry > maxT);                                                          \
-        else {                                                                                             \
-            float lo_ = fmaxf(enx - pad.x, fmaxf(eny - pad.y, enz - pad.z));                               \
-            float hi_ = fminf(exx + pad.x, fminf(exy + pad.y, exz + pad.z));                               \
-            pass = pass && !(lo_ > best.t) && !(hi_ < 0.0f);                                               \
+        if (ANY) {                                                                                         \
+            pass = pass && !(tentry > w.maxT) && !((texit + w.padt) < 0.0f);                               \
+            KEY = pass ? tentry : RT_INF;                                                                  \
+        } else {                                                                                           \
+            float lo_ = fmaxf(enx - w.pad.x, fmaxf(eny - w.pad.y, enz - w.pad.z));                         \
+            float hi_ = fminf(exx + w.pad.x, fminf(exy + w.pad.y, exz + w.pad.z));                         \
+            pass = pass && !(lo_ > w.best.t) && !(hi_ < 0.0f);                                             \
+            KEY = pass ? lo_ : RT_INF;                                                                     \
         }                                                                                                  \
-        KEY = pass ? (ANY ? tentry : fmaxf(enx - pad.x, fmaxf(eny - pad.y, enz - pad.z))) : RT_INF;        \
     }
-            RT_SLOT(0, lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ch.x, k0)
-            RT_SLOT(1, lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ch.y, k1)
-            RT_SLOT(2, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ch.z, k2)
-            RT_SLOT(3, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ch.w, k3)
+    RT_SLOT(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ch.x, k0)
+    RT_SLOT(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ch.y, k1)
+    RT_SLOT(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ch.z, k2)
+    RT_SLOT(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ch.w, k3)
 #undef RT_SLOT
-            uint32_t r0 = ch.x, r1 = ch.y, r2 = ch.z, r3 = ch.w;
-            if (!ANY) {
-                RT_CSWAP(k0, r0, k1, r1) RT_CSWAP(k2, r2, k3, r3) RT_CSWAP(k0, r0, k2, r2) RT_CSWAP(k1, r1, k3, r3) RT_CSWAP(k1, r1, k2, r2)
-                if (k3 < RT_INF) st.put(sp++, r3, k3);
-                if (k2 < RT_INF) st.put(sp++, r2, k2);
-                if (k1 < RT_INF) st.put(sp++, r1, k1);
-                if (k0 < RT_INF) { cur = r0; continue; }
-            } else {
-                if (k3 < RT_INF) st.put(sp++, r3, k3);
-                if (k2 < RT_INF) st.put(sp++, r2, k2);
-                if (k1 < RT_INF) st.put(sp++, r1, k1);
-                if (k0 < RT_INF) { cur = r0; continue; }
-            }
-        } else {
-            uint32_t first = cur & RT_LEAF_FIRST_MASK, cnt = ((cur >> 27) & 15u) + 1u;
-            for (uint32_t k = 0; k < cnt; k++) {
-                float t, u, v;
-                if (COUNT) c_tris++;
-                if (rt_tri_test(S.tris + first + k, o, dir, t, u, v)) {
-                    if (ANY) { if (t < maxT) return false; }
-                    else if (t < best.t || (t == best.t && (first + k) < best.rank)) {
-                        best.t = t; best.u = u; best.v = v; best.rank = first + k;
-                    }
+    uint32_t r0 = ch.x, r1 = ch.y, r2 = ch.z, r3 = ch.w;
+    if (!ANY) {
+        RT_CSWAP(k0, r0, k1, r1) RT_CSWAP(k2, r2, k3, r3) RT_CSWAP(k0, r0, k2, r2) RT_CSWAP(k1, r1, k3, r3) RT_CSWAP(k1, r1, k2, r2)
+    } else {  // no order needed: compact the passing children to the front
+        if (!(k2 < RT_INF)) { k2 = k3; r2 = r3; k3 = RT_INF; }
+        if (!(k1 < RT_INF)) { k1 = k2; r1 = r2; k2 = k3; r2 = r3; k3 = RT_INF; }
+        if (!(k0 < RT_INF)) { k0 = k1; r0 = r1; k1 = k2; r1 = r2; k2 = k3; r2 = r3; k3 = RT_INF; }
+    }
+    if (!RT_STACK_KEYS && __ballot(w.sp + 3u > (uint32_t)RT_STACK_LDS) == 0) {
+        // every lane has room in LDS for three more: store unconditionally, advance by the predicate
+        st.lds[w.sp * RT_BLOCK] = r3; w.sp += (k3 < RT_INF) ? 1u : 0u;
+        st.lds[w.sp * RT_BLOCK] = r2; w.sp += (k2 < RT_INF) ? 1u : 0u;
+        st.lds[w.sp * RT_BLOCK] = r1; w.sp += (k1 < RT_INF) ? 1u : 0u;
+    } else {
+        if (k3 < RT_INF) st.put(w.sp++, r3, k3);
+        if (k2 < RT_INF) st.put(w.sp++, r2, k2);
+        if (k1 < RT_INF) st.put(w.sp++, r1, k1);
+    }
+    if (k0 < RT_INF) { w.cur = r0; return true; }
+    return false;
+}
+// pop, dropping entries whose (padded) entry distance now lies beyond the best hit; false = stack empty
+template <bool ANY>
+__device__ __forceinline__ bool rt_pop(Walk& w, TravStack& st) {
+    while (w.sp) {
+        float key;
+        uint32_t c = st.get(--w.sp, key);
+        if (ANY || !(key > w.best.t)) { w.cur = c; return true; }
+    }
+    return false;
+}
+// One node or one leaf, then a pop.  Returns true when the walk is over (stack empty, or ANY found a blocker).
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ bool rt_wide_step(const DScene& S, Walk& w, TravStack& st, uint32_t& c_nodes, uint32_t& c_tris) {
+    const uint32_t cur = w.cur;
+    if (!(cur & RT_REF_LEAF)) {
+        const float4* q = reinterpret_cast<const float4*>(S.nodes4 + cur);
+        float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
+        uint4 ch = *reinterpret_cast<const uint4*>(q + 6);
+        if (COUNT) c_nodes++;
+        if (rt_node_eval<ANY>(w, st, lox, loy, loz, hix, hiy, hiz, ch)) return false;
+    } else {
+        uint32_t first = cur & RT_LEAF_FIRST_MASK, cnt = ((cur >> 27) & 15u) + 1u;
+        for (uint32_t k = 0; k < cnt; k++) {
+            float t, u, v;
+            if (COUNT) c_tris++;
+            if (rt_tri_test(S.tris + first + k, w.o, w.dir, t, u, v)) {
+                if (ANY) { if (t < w.maxT) { w.occluded = true; return true; } }
+                else if (t < w.best.t || (t == w.best.t && (first + k) < w.best.rank)) {
+                    w.best.t = t; w.best.u = u; w.best.v = v; w.best.rank = first + k;
                 }
             }
         }
-        // pop, dropping entries whose (padded) entry distance now lies beyond the best hit
-        bool got = false;
-        while (sp) { float key; uint32_t c = st.get(--sp, key); if (ANY || !(key > best.t)) { cur = c; got = true; break; } }
-        if (!got) break;
     }
-    return true;
+    return !rt_pop<ANY>(w, st);
 }
 
-// Scene::traverse (Scene.h:118): closest hit.  best.t == FLT_MAX <=> miss.
+// ---- the wave-voted step of rt_persistent_walk.  A wave whose lanes are part in nodes and part in leaves pays
+// for both code paths in rt_wide_step, each with a fraction of the lanes (PMC: ~26 % of VALU lanes live).  Here
+// the wave runs ONE of the two per step -- box tests for the lanes standing on a node, or one triangle for the
+// lanes standing in a leaf -- whichever serves more lanes per instruction; the others wait a step.
+// All 64 lanes call it (busy = this lane holds a walk).  Returns true when this lane's walk is over.
+#ifndef RT_VOTE_NUM
+#define RT_VOTE_NUM 1    // nodes go when (lanes on a node) * RT_VOTE_NUM >= (lanes in a leaf) * RT_VOTE_DEN; measured best near 1:1
+#define RT_VOTE_DEN 1
+#endif
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ bool rt_vote_step(const DScene& S, Walk& w, bool busy, TravStack& st, uint32_t& c_nodes, uint32_t& c_tris) {
+    const uint32_t cur = w.cur;
+    const bool inleaf = busy && (cur & RT_REF_LEAF) != 0;
+    const bool innode = busy && !(cur & RT_REF_LEAF);
+    const uint32_t nl = (uint32_t)__popcll(__ballot(inleaf)), nn = (uint32_t)__popcll(__ballot(innode));
+    if (nn * (uint32_t)RT_VOTE_NUM >= nl * (uint32_t)RT_VOTE_DEN) {
+        if (!innode) return false;
+        const float4* q = reinterpret_cast<const float4*>(S.nodes4 + cur);
+        float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
+        uint4 ch = *reinterpret_cast<const uint4*>(q + 6);
+        if (COUNT) c_nodes++;
+        if (rt_node_eval<ANY>(w, st, lox, loy, loz, hix, hiy, hiz, ch)) return false;
+        return !rt_pop<ANY>(w, st);
+    }
+    if (!inleaf) return false;
+    const uint32_t tri = cur & RT_LEAF_FIRST_MASK, left = (cur >> 27) & 15u;  // triangles left in the leaf after this one
+    const float4* q = reinterpret_cast<const float4*>(S.tris + tri);
+    float4 a = q[0], b = q[1], c = q[2], e = q[3];
+    float t, u, v;
+    if (COUNT) c_tris++;
+    if (rt_tri_eval_all(a, b, c, e, w.o, w.dir, t, u, v)) {
+        if (ANY) { if (t < w.maxT) { w.occluded = true; return true; } }
+        else if (t < w.best.t || (t == w.best.t && tri < w.best.rank)) { w.best.t = t; w.best.u = u; w.best.v = v; w.best.rank = tri; }
+    }
+    if (left) { w.cur = RT_REF_LEAF | ((left - 1u) << 27) | (tri + 1u); return false; }
+    return !rt_pop<ANY>(w, st);
+}
+
+// Scene::traverse (Scene.h:118), set-up half: returns true when the result is already known (w.best), false when
+// the lane now holds a 4-wide walk to step.  best.t == FLT_MAX <=> miss.
 template <bool COUNT>
-__device__ __forceinline__ void rt_closest(const DScene& S, f3 o, f3 dir, int mode, HitRec& best, TravStack& st,
-                                           uint32_t* spill2, uint32_t gstride, uint32_t& cn, uint32_t& ct, uint32_t& cexact) {
-    best.t = RT_FLT_MAX; best.u = 0; best.v = 0; best.rank = 0xFFFFFFFFu;
-    if (S.root_ref == RT_REF_EMPTY) return;
+__device__ __forceinline__ bool rt_closest_begin(const DScene& S, f3 o, f3 dir, int mode, Walk& w, uint32_t* spill2, uint32_t gstride,
+                                                 uint32_t& cn, uint32_t& ct, uint32_t& cexact) {
+    w.best.t = RT_FLT_MAX; w.best.u = 0; w.best.v = 0; w.best.rank = 0xFFFFFFFFu;
+    if (S.root_ref == RT_REF_EMPTY) return true;
     // dir == (0,0,0) (what pathTrace shoots after a BSDF returned pdf 0 / wi 0, e.g. Materials.h:319-324): Dot(n, dir)
     // is 0 for every triangle, so Triangle::rayIntersect rejects all of them (Geometry.h:118) -- a miss, whatever
     // boxes the reference would have walked through on the way.
-    if (mode == 0 && dir.x == 0.0f && dir.y == 0.0f && dir.z == 0.0f) return;
+    if (mode == 0 && dir.x == 0.0f && dir.y == 0.0f && dir.z == 0.0f) return true;
     f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-    if (mode == 0 && rt_ray_is_tame(inv)) {
-        rt_walk_wide_v1<false, COUNT>(S, o, dir, inv, 0.0f, best, st, cn, ct);
+    if (mode == 0 && rt_ray_is_tame(inv)) { rt_walk_init(S, w, o, dir, inv, 0.0f); return false; }
+    if (COUNT) cexact++;
+    rt_walk_reference<false, COUNT>(S, o, dir, 0.0f, w.best, spill2, gstride, cn, ct);
+    return true;
+}
+// Scene::visible (Scene.h:169-178), set-up half: true when `visible` is already known.
+template <bool COUNT>
+__device__ __forceinline__ bool rt_visible_begin(const DScene& S, f3 p1, f3 p2, int mode, Walk& w, bool& visible, uint32_t* spill2,
+                                                 uint32_t gstride, uint32_t& cn, uint32_t& ct, uint32_t& cexact) {
+    f3 dir = p2 - p1;
+    float maxT = len3(dir) - (2.0f * RT_EPSILON);
+    dir = norm3(dir);
+    f3 o = p1 + (dir * RT_EPSILON);
+    visible = true;
+    if (S.root_ref == RT_REF_EMPTY) return true;
+    f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+    if (mode == 0 && rt_ray_is_tame(inv)) { rt_walk_init(S, w, o, dir, inv, maxT); return false; }
+    if (COUNT) cexact++;
+    HitRec dummy;
+    visible = rt_walk_reference<true, COUNT>(S, o, dir, maxT, dummy, spill2, gstride, cn, ct);
+    return true;
+}
+
+// ---- persistent traversal with lane refill (Aila & Laine's "persistent while-while" idea at wave64 width).
+// With one ray per lane per 64-ray chunk a wave runs until its slowest ray is done; PMC counters put the average
+// number of live lanes per VALU instruction at ~11 of 64 that way.  Here a wave keeps a private pool of item
+// indices (one work atomic per RT_FETCH_CHUNKS*64 items); whenever at least RT_REFILL_IDLE lanes are idle the finished
+// lanes retire their result together and every idle lane is handed the next item of the pool.
+//   Job:    bool load(uint32_t item, f3& a, f3& b)   -- closest: origin, direction; any: p1, p2.  false = nothing to trace
+//           void retire(uint32_t item, const Walk& w, bool visible)
+//   Source: bool next(uint32_t& begin, uint32_t& end) -- wave-uniform grant of items [begin, end), false when drained
+// Which lane traces which item only affects speed: every item is loaded, traced and retired by exactly one lane.
+#ifndef RT_REFILL_IDLE
+#define RT_REFILL_IDLE 16
+#endif
+
+template <bool ANY, bool COUNT, class Job, class Source>
+__device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, Source& src, int mode, TravStack& st, uint32_t* spill2,
+                                                   uint32_t gstride, uint32_t& cn, uint32_t& ct, uint32_t& cx, DCounters* counters) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t c_slots = 0, c_busy = 0;
+    Walk w;
+    uint32_t item = 0;
+    bool busy = false, done = false, visible = true;
+    uint32_t pb = 0, pe = 0;   // the wave's pool of granted items (wave-uniform)
+    bool drained = false;      // wave-uniform
+    for (;;) {
+        unsigned long long idle = __ballot(!busy);
+        uint32_t nidle = (uint32_t)__popcll(idle);
+        if (drained ? (nidle == 64u) : (nidle >= (uint32_t)RT_REFILL_IDLE)) {
+            if (done) { job.retire(item, w, visible); done = false; }
+            if (drained) break;
+            if (pb >= pe) {
+                if (!src.next(pb, pe)) { drained = true; continue; }
+            }
+            uint32_t take = pe - pb;
+            take = take < nidle ? take : nidle;
+            uint32_t my = (uint32_t)__popcll(idle & ((1ULL << lane) - 1ULL));
+            if (!busy && my < take) {
+                item = pb + my;
+                f3 a, b;
+                if (job.load(item, a, b)) {
+                    bool fin = ANY ? rt_visible_begin<COUNT>(S, a, b, mode, w, visible, spill2, gstride, cn, ct, cx)
+                                   : rt_closest_begin<COUNT>(S, a, b, mode, w, spill2, gstride, cn, ct, cx);
+                    busy = !fin; done = fin;
+                }
+            }
+            pb += take;
+            continue;  // re-count: short grants and dead items leave lanes idle
+        }
+        if (COUNT) { c_slots++; c_busy += busy ? 1u : 0u; }
+        if (rt_vote_step<ANY, COUNT>(S, w, busy, st, cn, ct)) {
+            busy = false; done = true;
+            if (ANY) visible = !w.occluded;
+        }
     }
-    else { if (COUNT) cexact++; rt_walk_reference<false, COUNT>(S, o, dir, 0.0f, best, spill2, gstride, cn, ct); }
+    if (COUNT) {
+        atomicAdd(ANY ? &counters->any_slots : &counters->slots, (unsigned long long)c_slots);
+        atomicAdd(ANY ? &counters->any_busy : &counters->busy, (unsigned long long)c_busy);
+    }
+}
+
+// Scene::traverse (Scene.h:118): closest hit, one ray per lane start to finish.
+template <bool COUNT>
+__device__ __forceinline__ void rt_closest(const DScene& S, f3 o, f3 dir, int mode, HitRec& best, TravStack& st,
+                                           uint32_t* spill2, uint32_t gstride, uint32_t& cn, uint32_t& ct, uint32_t& cexact) {
+    Walk w;
+    if (!rt_closest_begin<COUNT>(S, o, dir, mode, w, spill2, gstride, cn, ct, cexact))
+        while (!rt_wide_step<false, COUNT>(S, w, st, cn, ct)) {}
+    best = w.best;
 }
 
 // Scene::visible (Scene.h:169-178)
 template <bool COUNT>
 __device__ __forceinline__ bool rt_visible(const DScene& S, f3 p1, f3 p2, int mode, TravStack& st, uint32_t* spill2, uint32_t gstride,
                                            uint32_t& cn, uint32_t& ct, uint32_t& cexact) {
-    f3 dir = p2 - p1;
-    float maxT = len3(dir) - (2.0f * RT_EPSILON);
-    dir = norm3(dir);
-    f3 o = p1 + (dir * RT_EPSILON);
-    if (S.root_ref == RT_REF_EMPTY) return true;
-    f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-    HitRec dummy;
-    if (mode == 0 && rt_ray_is_tame(inv)) return rt_walk_wide<true, COUNT>(S, o, dir, inv, maxT, dummy, st, cn, ct);
-    if (COUNT) cexact++;
-    return rt_walk_reference<true, COUNT>(S, o, dir, maxT, dummy, spill2, gstride, cn, ct);
+    Walk w;
+    bool visible;
+    if (rt_visible_begin<COUNT>(S, p1, p2, mode, w, visible, spill2, gstride, cn, ct, cexact)) return visible;
+    while (!rt_wide_step<true, COUNT>(S, w, st, cn, ct)) {}
+    return !w.occluded;
 }

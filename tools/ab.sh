@@ -5,6 +5,7 @@ for lib in "$@"; do
   python - "$lib" <<'PY'
 import json,sys
 d=json.load(open('/tmp/ab.json'))
-print(sys.argv[1], 'Mrays/s %.1f ms/spp %.2f'%(d['value'], d['ms_per_step']), {k:round(v,1) for k,v in d['kernel_ms'].items() if v>1})
+print(sys.argv[1], 'Mrays/s %.1f ms/spp %.2f'%(d['value'], d['ms_per_step']), {k:round(v,1) for k,v in d['kernel_ms'].items() if v>1},
+      'occ ext %.3f con %.3f' % (d['roofline'].get('lane_occupancy', 0), d['connect'].get('lane_occupancy', 0)))
 PY
 done
