@@ -81,8 +81,9 @@ __device__ __host__ __forceinline__ float rt_rng_next(Rng& r) {
 // irrelevant while it waited on the stack is dropped at pop time without fetching its node / triangles.  References
 // and keys live in two lane-interleaved 32-bit planes (LDS: [2][RT_STACK_LDS][RT_BLOCK]).
 #define RT_STACK_WORDS ((RT_STACK_KEYS ? 2 : 1) * RT_STACK_LDS * RT_BLOCK)
+typedef __attribute__((address_space(3))) uint32_t rt_lds_u32;  // explicit LDS address space: keeps pops ds_read, not flat_load
 struct TravStack {
-    uint32_t* lds;     // &lds_stack[threadIdx.x]
+    rt_lds_u32* lds;   // &lds_stack[threadIdx.x]
     uint32_t* glob;    // &spill[global thread id], may be null when the scene's bound fits LDS
     uint32_t gstride;  // total threads of the launch
     uint32_t gkeys;    // offset (in words) of the key plane inside the spill array
@@ -97,18 +98,22 @@ struct TravStack {
         }
     }
     __device__ __forceinline__ uint32_t get(uint32_t sp, float& key) const {
-        if (sp < RT_STACK_LDS) {
-            key = RT_STACK_KEYS ? __uint_as_float(lds[(RT_STACK_LDS + sp) * RT_BLOCK]) : -RT_INF;
-            return lds[sp * RT_BLOCK];
+        // the LDS read is unconditional (clamped index) so that it stays a ds_read: with one load per branch the
+        // compiler sinks both into a single flat_load, which is slower than LDS for the common case
+        const uint32_t i = sp < RT_STACK_LDS ? sp : RT_STACK_LDS - 1u;
+        uint32_t v = lds[i * RT_BLOCK];
+        key = RT_STACK_KEYS ? __uint_as_float(lds[(RT_STACK_LDS + i) * RT_BLOCK]) : -RT_INF;
+        if (sp >= RT_STACK_LDS) {
+            size_t o = (size_t)(sp - RT_STACK_LDS) * gstride;
+            v = glob[o];
+            if (RT_STACK_KEYS) key = __uint_as_float(glob[o + gkeys]);
         }
-        size_t o = (size_t)(sp - RT_STACK_LDS) * gstride;
-        key = RT_STACK_KEYS ? __uint_as_float(glob[o + gkeys]) : -RT_INF;
-        return glob[o];
+        return v;
     }
 };
 #define RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, max_stack4)                    \
     TravStack st;                                                                             \
-    st.lds = lds_stack + threadIdx.x; st.glob = spill4 ? spill4 + gtid : nullptr; st.gstride = gstride; \
+    st.lds = (rt_lds_u32*)(lds_stack + threadIdx.x); st.glob = spill4 ? spill4 + gtid : nullptr; st.gstride = gstride; \
     st.gkeys = (max_stack4 > RT_STACK_LDS ? (max_stack4 - RT_STACK_LDS) : 0u) * gstride;
 
 struct HitRec { float t, u, v; uint32_t rank; };
@@ -235,10 +240,15 @@ __device__ __forceinline__ void rt_walk_init(const DScene& S, Walk& w, f3 o, f3 
     w.cur = S.root_ref; w.sp = 0; w.occluded = false;
 }
 // Box tests of one 4-wide node: pushes the passing children but the nearest, which becomes w.cur (returns true).
+// (Writing the slab arithmetic on child pairs so that it compiles to v_pk_add_f32 / v_pk_mul_f32 measured 20 % slower
+// in k_extend: the register shuffling costs more than the packed ops save; the build also passes -fno-slp-vectorize.)
+#ifndef RT_POP_FAST
+#define RT_POP_FAST 1
+#endif
 template <bool ANY>
 __device__ __forceinline__ bool rt_node_eval(Walk& w, TravStack& st, float4 lox, float4 loy, float4 loz, float4 hix, float4 hiy, float4 hiz, uint4 ch) {
-    const f3 o = w.o, inv = w.inv;
     float k0, k1, k2, k3;
+    const f3 o = w.o, inv = w.inv;
 #define RT_SLOT(LX, LY, LZ, HX, HY, HZ, CH, KEY)                                                         \
     {                                                                                                      \
         float ax = (LX - o.x) * inv.x, bx = (HX - o.x) * inv.x;                                            \
@@ -288,6 +298,13 @@ __device__ __forceinline__ bool rt_node_eval(Walk& w, TravStack& st, float4 lox,
 // pop, dropping entries whose (padded) entry distance now lies beyond the best hit; false = stack empty
 template <bool ANY>
 __device__ __forceinline__ bool rt_pop(Walk& w, TravStack& st) {
+    if (!RT_STACK_KEYS && RT_POP_FAST) {
+        if (w.sp == 0) return false;
+        --w.sp;
+        float key;
+        w.cur = st.get(w.sp, key);
+        return true;
+    }
     while (w.sp) {
         float key;
         uint32_t c = st.get(--w.sp, key);
@@ -327,8 +344,8 @@ __device__ __forceinline__ bool rt_wide_step(const DScene& S, Walk& w, TravStack
 // lanes standing in a leaf -- whichever serves more lanes per instruction; the others wait a step.
 // All 64 lanes call it (busy = this lane holds a walk).  Returns true when this lane's walk is over.
 #ifndef RT_VOTE_NUM
-#define RT_VOTE_NUM 1    // nodes go when (lanes on a node) * RT_VOTE_NUM >= (lanes in a leaf) * RT_VOTE_DEN; measured best near 1:1
-#define RT_VOTE_DEN 1
+#define RT_VOTE_NUM 3    // nodes go when (lanes on a node) * RT_VOTE_NUM >= (lanes in a leaf) * RT_VOTE_DEN; measured best near 1:1
+#define RT_VOTE_DEN 2
 #endif
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ bool rt_vote_step(const DScene& S, Walk& w, bool busy, TravStack& st, uint32_t& c_nodes, uint32_t& c_tris) {
