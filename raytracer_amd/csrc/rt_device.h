@@ -228,6 +228,7 @@ struct Walk {
     float maxT, padt;  // any hit
     HitRec best;
     uint32_t cur, sp;
+    uint32_t sx, sy, sz;   // 48 where 1/dir is negative on that axis, else 0: byte distance from a node's lo plane row to its hi row
     bool occluded;
 };
 __device__ __forceinline__ void rt_walk_init(const DScene& S, Walk& w, f3 o, f3 dir, f3 inv, float maxT) {
@@ -237,6 +238,7 @@ __device__ __forceinline__ void rt_walk_init(const DScene& S, Walk& w, f3 o, f3 
     w.pad = mk3(delta * fabsf(inv.x), delta * fabsf(inv.y), delta * fabsf(inv.z));
     w.padt = delta * fmaxf(fabsf(inv.x), fmaxf(fabsf(inv.y), fabsf(inv.z)));
     w.maxT = maxT;
+    w.sx = inv.x < 0.0f ? 48u : 0u; w.sy = inv.y < 0.0f ? 48u : 0u; w.sz = inv.z < 0.0f ? 48u : 0u;
     w.cur = S.root_ref; w.sp = 0; w.occluded = false;
 }
 // Box tests of one 4-wide node: pushes the passing children but the nearest, which becomes w.cur (returns true).
@@ -245,20 +247,32 @@ __device__ __forceinline__ void rt_walk_init(const DScene& S, Walk& w, f3 o, f3 
 #ifndef RT_POP_FAST
 #define RT_POP_FAST 1
 #endif
+// The node's plane rows are fetched near-plane first: on an axis where 1/dir is negative the entry plane is hi, so
+// the lane reads the hi row where the others read lo (an address choice, not a select).  For lo <= hi and a finite
+// non-NaN 1/dir, (near - o) * inv == Min((lo - o) * inv, (hi - o) * inv) bit for bit (rounding is monotonic), which is
+// AABB::rayAABB's tmin/tmax ordering (Geometry.h:213-221) without the six min/max per child.  Unused child slots
+// hold NaN boxes and fail `tentry <= texit` by themselves.
 template <bool ANY>
-__device__ __forceinline__ bool rt_node_eval(Walk& w, TravStack& st, float4 lox, float4 loy, float4 loz, float4 hix, float4 hiy, float4 hiz, uint4 ch) {
+__device__ __forceinline__ bool rt_node_eval(const DScene& S, Walk& w, TravStack& st) {
+    const char* nb = reinterpret_cast<const char*>(S.nodes4);
+    const uint32_t base = w.cur << 7;   // < 2^32: the host caps the wide tree at 2^25 nodes
+    const float4 nx = *reinterpret_cast<const float4*>(nb + (base + w.sx));
+    const float4 ny = *reinterpret_cast<const float4*>(nb + ((base + 16u) + w.sy));
+    const float4 nz = *reinterpret_cast<const float4*>(nb + ((base + 32u) + w.sz));
+    const float4 fx = *reinterpret_cast<const float4*>(nb + ((base + 48u) - w.sx));
+    const float4 fy = *reinterpret_cast<const float4*>(nb + ((base + 64u) - w.sy));
+    const float4 fz = *reinterpret_cast<const float4*>(nb + ((base + 80u) - w.sz));
+    const uint4 ch = *reinterpret_cast<const uint4*>(nb + (base + 96u));
     float k0, k1, k2, k3;
     const f3 o = w.o, inv = w.inv;
-#define RT_SLOT(LX, LY, LZ, HX, HY, HZ, CH, KEY)                                                         \
+#define RT_SLOT(NX, NY, NZ, FX, FY, FZ, KEY)                                                             \
     {                                                                                                      \
-        float ax = (LX - o.x) * inv.x, bx = (HX - o.x) * inv.x;                                            \
-        float ay = (LY - o.y) * inv.y, by = (HY - o.y) * inv.y;                                            \
-        float az = (LZ - o.z) * inv.z, bz = (HZ - o.z) * inv.z;                                            \
-        float enx = fminf(ax, bx), eny = fminf(ay, by), enz = fminf(az, bz);                               \
-        float exx = fmaxf(ax, bx), exy = fmaxf(ay, by), exz = fmaxf(az, bz);                               \
+        float enx = (NX - o.x) * inv.x, exx = (FX - o.x) * inv.x;                                          \
+        float eny = (NY - o.y) * inv.y, exy = (FY - o.y) * inv.y;                                          \
+        float enz = (NZ - o.z) * inv.z, exz = (FZ - o.z) * inv.z;                                          \
         float tentry = fmaxf(enx, fmaxf(eny, enz));                                                        \
         float texit = fminf(exx, fminf(exy, exz));                                                         \
-        bool pass = (tentry <= texit) && (CH != RT_REF_EMPTY);                                             \
+        bool pass = (tentry <= texit);                                                                     \
         if (ANY) {                                                                                         \
             pass = pass && !(tentry > w.maxT) && !((texit + w.padt) < 0.0f);                               \
             KEY = pass ? tentry : RT_INF;                                                                  \
@@ -269,10 +283,10 @@ __device__ __forceinline__ bool rt_node_eval(Walk& w, TravStack& st, float4 lox,
             KEY = pass ? lo_ : RT_INF;                                                                     \
         }                                                                                                  \
     }
-    RT_SLOT(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ch.x, k0)
-    RT_SLOT(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ch.y, k1)
-    RT_SLOT(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ch.z, k2)
-    RT_SLOT(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ch.w, k3)
+    RT_SLOT(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, k0)
+    RT_SLOT(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, k1)
+    RT_SLOT(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, k2)
+    RT_SLOT(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, k3)
 #undef RT_SLOT
     uint32_t r0 = ch.x, r1 = ch.y, r2 = ch.z, r3 = ch.w;
     if (!ANY) {
@@ -317,11 +331,8 @@ template <bool ANY, bool COUNT>
 __device__ __forceinline__ bool rt_wide_step(const DScene& S, Walk& w, TravStack& st, uint32_t& c_nodes, uint32_t& c_tris) {
     const uint32_t cur = w.cur;
     if (!(cur & RT_REF_LEAF)) {
-        const float4* q = reinterpret_cast<const float4*>(S.nodes4 + cur);
-        float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
-        uint4 ch = *reinterpret_cast<const uint4*>(q + 6);
         if (COUNT) c_nodes++;
-        if (rt_node_eval<ANY>(w, st, lox, loy, loz, hix, hiy, hiz, ch)) return false;
+        if (rt_node_eval<ANY>(S, w, st)) return false;
     } else {
         uint32_t first = cur & RT_LEAF_FIRST_MASK, cnt = ((cur >> 27) & 15u) + 1u;
         for (uint32_t k = 0; k < cnt; k++) {
@@ -355,11 +366,8 @@ __device__ __forceinline__ bool rt_vote_step(const DScene& S, Walk& w, bool busy
     const uint32_t nl = (uint32_t)__popcll(__ballot(inleaf)), nn = (uint32_t)__popcll(__ballot(innode));
     if (nn * (uint32_t)RT_VOTE_NUM >= nl * (uint32_t)RT_VOTE_DEN) {
         if (!innode) return false;
-        const float4* q = reinterpret_cast<const float4*>(S.nodes4 + cur);
-        float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
-        uint4 ch = *reinterpret_cast<const uint4*>(q + 6);
         if (COUNT) c_nodes++;
-        if (rt_node_eval<ANY>(w, st, lox, loy, loz, hix, hiy, hiz, ch)) return false;
+        if (rt_node_eval<ANY>(S, w, st)) return false;
         return !rt_pop<ANY>(w, st);
     }
     if (!inleaf) return false;

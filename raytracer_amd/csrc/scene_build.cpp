@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <limits>
 #include <chrono>
 
 namespace {
@@ -182,8 +183,14 @@ struct Collapser {
         n.child[k] = ref;
     }
     static DNode4 empty_node() {
+        // an unused child slot carries a NaN box: every slab product is NaN, `tentry <= texit` is false, and the walk
+        // needs no separate "slot in use" test
         DNode4 n; memset(&n, 0, sizeof(n));
-        for (int k = 0; k < 4; k++) n.child[k] = RT_REF_EMPTY;
+        const float qnan = std::numeric_limits<float>::quiet_NaN();
+        for (int k = 0; k < 4; k++) {
+            n.child[k] = RT_REF_EMPTY;
+            n.lox[k] = n.loy[k] = n.loz[k] = n.hix[k] = n.hiy[k] = n.hiz[k] = qnan;
+        }
         return n;
     }
     // A leaf range longer than RT_LEAF_MAX becomes a small subtree of slots that all carry the leaf's box.
@@ -345,6 +352,7 @@ bool host_scene_build(const rt_scene_desc& d, HostScene& hs, std::string& err) {
             col.emit(0, need);
         }
         hs.max_stack4 = need + 2;
+        if (hs.nodes4.size() > (1u << 25)) { err = "wide BVH exceeds 2^25 nodes (32-bit node offsets)"; return false; }
     }
 
     // light list: background first if it has power (Scene.h:164), then emissive triangles in caller order (Scene.h:107)
