@@ -47,6 +47,8 @@ def lib():
         L.orc_generate_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.orc_project.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_project.restype = C.c_int
+        L.orc_mlt_render.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]
+        L.orc_mlt_render.restype = None
         L.orc_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int, C.POINTER(Stats)]
         L.orc_vpl_trace.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
         L.orc_vpl_trace.restype = C.c_int
@@ -153,6 +155,13 @@ class OracleScene:
         self.L.orc_render(self.h, mode, spp, seed, first_sample, film.ctypes.data, threads, C.byref(st))
         stats = dict(closest_rays=st.closest_rays, any_rays=st.any_rays, nodes_visited=st.nodes_visited, tris_tested=st.tris_tested)
         return film, stats
+
+    def mlt_render(self, spp=1, seed=1, first_sample=0, film=None):
+        """renderSTMLT (Renderer.h:353): 100 000 proposals per spp, un-normalised film sum."""
+        if film is None:
+            film = np.zeros((self.height, self.width, 3), np.float32)
+        self.L.orc_mlt_render(self.h, spp, seed, first_sample, film.ctypes.data)
+        return film
 
     def vpl_trace(self, n, seed=1):
         return self.L.orc_vpl_trace(self.h, n, seed)

@@ -1190,6 +1190,62 @@ static Col aov(Ctx* c, int mode, V3 o, V3 dir, Rng* rng) {
     return mode == 10 ? bg_evaluate(s, dir) : col(0, 0, 0);
 }
 
+/* ---------------------------------------------------------------- PSSMLT (ref: Renderer.h:964-1063, :353-370; Sampling.h:43-139)
+ * What the upstream sampler does, read off its code: PSS::next (Sampling.h:60-67) hands out coordinate
+ * currentIndex++ and currentIndex is only ever reset by PSS::reset (largeStep, :118-122).  A small step perturbs the
+ * coordinates already handed out (smallStepPerturb, :85-94) and the next nextPSSP() indexes past them, pushing a
+ * fresh uniform: every proposal's (x, y) is a fresh uniform draw whether the step was "small" or "large".
+ * pathTrace(x, y, sampler) takes all its numbers from sampler->next() == PSSSampler::random (:132-134), not from
+ * the primary sample space.  So proposals are independent of the chain state; the mutated coordinates are never
+ * read and are not restated.  What remains is restated in upstream's order: b from M = 100 paths (:995-1006), an
+ * initial state (:1022), 100 000 proposals per renderSTMLT call (:357) with the large/small splat weights
+ * (:1040-1047) and the acceptance draw (:1053).
+ * Shared number spec (GPU and oracle): path i of sample k draws from stream 2 with pixel = i (i < 100: the b
+ * estimate, i = 100: initial state, i = 101 + j: proposal j); the chain's two draws per proposal come from stream 4. */
+#define MLT_M 100
+#define MLT_PROPOSALS 100000
+static float mlt_acceptance(Col current, Col proposed) { /* Renderer.h:965-973 */
+    float cl = clum(current), pl = clum(proposed);
+    if (cl <= 0.0f) return 1.0f;
+    if (pl <= 0.0f) return 0.0f;
+    float r = pl / cl;
+    return (r < 1.0f) ? r : 1.0f; /* (std::min)(1.0f, r) */
+}
+static Col mlt_path(Ctx* c, uint64_t seed, uint64_t sample, uint32_t index, float* x, float* y) { /* genPathC / genPathP, Renderer.h:978-992 */
+    const orc_scene* s = c->s;
+    Rng rng = rng_make(seed, sample, index, 2);
+    *x = rng_next(&rng) * s->width;
+    *y = rng_next(&rng) * s->height;
+    float u1 = rng_next(&rng), u2 = rng_next(&rng);
+    V3 o, d;
+    camera_ray(s, *x + u1, *y + u2, &o, &d); /* Renderer.h:205 */
+    return path_trace(c, o, d, &rng, 0);
+}
+void orc_mlt_render(orc_scene* s, int spp, uint64_t seed, uint64_t first, float* film) {
+    int W = (int)s->width, H = (int)s->height;
+    Ctx c; memset(&c, 0, sizeof(c)); c.s = s;
+    const float largeStepProb = 0.3f; /* Renderer.h:1010 */
+    for (int k = 0; k < spp; k++) {
+        uint64_t sample = first + (uint64_t)k;
+        float b = 0.0f, x, y;
+        for (int i = 0; i < MLT_M; i++) b += clum(mlt_path(&c, seed, sample, (uint32_t)i, &x, &y));
+        b /= MLT_M;
+        if (b <= 0.0f) b = 1.0f;
+        float cx, cy, px, py;
+        Col current = mlt_path(&c, seed, sample, MLT_M, &cx, &cy);
+        Rng chain = rng_make(seed, sample, 0, 4);
+        for (int i = 0; i < MLT_PROPOSALS; i++) {
+            int largeStep = rng_next(&chain) < largeStepProb;
+            Col proposed = mlt_path(&c, seed, sample, (uint32_t)(MLT_M + 1 + i), &px, &py);
+            float a = mlt_acceptance(current, proposed);
+            if (largeStep) film_add(film, W, H, px, py, cdivf(cmulf(proposed, a), (b + largeStepProb * clum(proposed))), 0);
+            else film_add(film, W, H, px, py, cdivf(cmulf(proposed, a), b), 0);
+            film_add(film, W, H, cx, cy, cdivf(cmulf(current, (1.0f - a)), b), 0);
+            if (rng_next(&chain) < a) { current = proposed; cx = px; cy = py; }
+        }
+    }
+}
+
 /* ---------------------------------------------------------------- render driver (ref: Renderer.h:397-428, :516-545, :327-351) */
 typedef struct {
     orc_scene* s; int mode, spp; uint64_t seed, first; float* film;

@@ -502,6 +502,88 @@ __global__ __launch_bounds__(256) void k_accumulate(RBuf R, float* film, uint32_
     }
 }
 
+// ------------------------------------------------------------------------------------------------ PSSMLT
+// PSSMLTRender (Renderer.h:1013-1063) as upstream's sampler actually behaves (Sampling.h:60-67, :85-94, :118-139):
+// PSS::next never re-reads a perturbed coordinate (currentIndex only resets on a large step, which also clears the
+// vector), and pathTrace draws from PSSSampler::random, so every proposal is a fresh uniform (x, y) plus an
+// independent path.  That makes one spp = 100 paths for b + 1 initial state + 100 000 proposals that can all be
+// traced at once by the wavefront path tracer, followed by upstream's sequential accept/splat loop over their
+// radiances -- one chain per spp, one lane per chain.  Path p = index * n_chains + chain (coalesced for the chain
+// lanes); numbers: stream 2 / pixel = index for the path, stream 4 for the chain's two draws per proposal.
+#define RT_MLT_M 100u             // Renderer.h:975
+#define RT_MLT_PROPOSALS 100000u  // Renderer.h:357
+#define RT_MLT_PATHS (RT_MLT_M + 1u + RT_MLT_PROPOSALS)
+__global__ __launch_bounds__(256) void k_mlt_generate(DScene S, RBuf R, uint32_t n, uint32_t chains, uint64_t seed, uint64_t first_sample) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint32_t index = i / chains, c = i - index * chains;
+        Rng rng; rng.key = rt_rng_key(seed, first_sample + c, index, 2); rng.ctr = 0;
+        float x = rt_rng_next(rng) * S.cam.width;   // genPathC / genPathP (Renderer.h:978-992)
+        float y = rt_rng_next(rng) * S.cam.height;
+        float u1 = rt_rng_next(rng), u2 = rt_rng_next(rng);
+        f3 o, d;
+        camera_ray(S.cam, x + u1, y + u2, o, d);    // pathTrace(px, py, sampler) (Renderer.h:203-207)
+        R.ray_o[i] = make_float4(o.x, o.y, o.z, __uint_as_float(rng.key));
+        R.ray_d[i] = make_float4(d.x, d.y, d.z, __uint_as_float(rng.ctr));
+        R.thr[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(RT_FLAG_CANHIT));
+        R.rad[i] = make_float4(0, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ float mlt_acceptance(col3 current, col3 proposed) {  // calculateAcceptance (Renderer.h:965-973)
+    float cl = lumc(current), pl = lumc(proposed);
+    if (cl <= 0.0f) return 1.0f;
+    if (pl <= 0.0f) return 0.0f;
+    float r = pl / cl;
+    return (r < 1.0f) ? r : 1.0f;  // (std::min)(1.0f, r)
+}
+__device__ __forceinline__ void film_splat(float* film, const DCamera& cam, float x, float y, col3 c) {  // Film::splat, BoxFilter (Imaging.h:224)
+    int px = (int)x, py = (int)y;
+    if (px >= 0 && px < cam.iw && py >= 0 && py < cam.ih) {
+        float* f = film + ((size_t)py * cam.iw + px) * 3;
+        atomicAdd(f + 0, c.r); atomicAdd(f + 1, c.g); atomicAdd(f + 2, c.b);
+    }
+}
+__device__ __forceinline__ void mlt_xy(const DScene& S, uint64_t seed, uint64_t sample, uint32_t index, float& x, float& y) {
+    Rng rng; rng.key = rt_rng_key(seed, sample, index, 2); rng.ctr = 0;
+    x = rt_rng_next(rng) * S.cam.width;
+    y = rt_rng_next(rng) * S.cam.height;
+}
+__global__ __launch_bounds__(64) void k_mlt_chain(DScene S, RBuf R, float* film, uint32_t chains, uint64_t seed, uint64_t first_sample) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= chains) return;
+    const uint64_t sample = first_sample + c;
+    const float largeStepProb = 0.3f;  // Renderer.h:1010
+    float b = 0.0f;                    // getNormalization (Renderer.h:995-1006)
+    for (uint32_t i = 0; i < RT_MLT_M; i++) {
+        float4 L = R.rad[(size_t)i * chains + c];
+        b += lumc(mkc(L.x, L.y, L.z));
+    }
+    b /= (float)RT_MLT_M;
+    if (b <= 0.0f) b = 1.0f;
+    float4 L0 = R.rad[(size_t)RT_MLT_M * chains + c];
+    col3 current = mkc(L0.x, L0.y, L0.z);
+    float cx, cy;
+    mlt_xy(S, seed, sample, RT_MLT_M, cx, cy);
+    Rng chain; chain.key = rt_rng_key(seed, sample, 0, 4); chain.ctr = 0;
+    constexpr uint32_t U = 8;  // the proposals' radiances do not depend on the chain: fetch them U at a time
+    for (uint32_t i0 = 0; i0 < RT_MLT_PROPOSALS; i0 += U) {
+        float4 buf[U];
+#pragma unroll
+        for (uint32_t j = 0; j < U; j++) buf[j] = R.rad[(size_t)(RT_MLT_M + 1u + i0 + j) * chains + c];
+#pragma unroll
+        for (uint32_t j = 0; j < U; j++) {
+            bool largeStep = rt_rng_next(chain) < largeStepProb;
+            col3 proposed = mkc(buf[j].x, buf[j].y, buf[j].z);
+            float px, py;
+            mlt_xy(S, seed, sample, RT_MLT_M + 1u + i0 + j, px, py);
+            float a = mlt_acceptance(current, proposed);
+            if (largeStep) film_splat(film, S.cam, px, py, (proposed * a) / (b + largeStepProb * lumc(proposed)));
+            else film_splat(film, S.cam, px, py, (proposed * a) / b);
+            film_splat(film, S.cam, cx, cy, (current * (1.0f - a)) / b);
+            if (rt_rng_next(chain) < a) { current = proposed; cx = px; cy = py; }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ AOV / direct
 // albedo(), viewNormals(), direct() (Renderer.h:257-296): one ray through the pixel centre (Renderer.h:590).
 __global__ __launch_bounds__(RT_BLOCK) void k_aov(DScene S, RBuf R, Ctl* ctl, int mode, uint64_t seed, uint64_t first_sample, uint32_t n,
@@ -882,7 +964,7 @@ extern "C" int rt_renderer_create(rt_scene* scene, rt_renderer** out) {
     R.np_pad = R.tiles_x * tiles_y * 64;
     // batch: as many samples per pixel as fit ~16 M paths (about 3 GB of wavefront state; the card has 288 GB)
     r->batch_max = std::max<uint32_t>(1, std::min<uint32_t>(64, (16u << 20) / R.np_pad));
-    R.cap = R.np_pad * r->batch_max;
+    R.cap = std::max<uint32_t>(R.np_pad * r->batch_max, (RT_MLT_PATHS + 63u) / 64u * 64u);  // room for at least one PSSMLT chain
     auto fail = [&](int rc) { rt_renderer_destroy(r); return rc; };
     int rc;
     if (hipStreamCreate(&r->stream) != hipSuccess) { rt_set_error("rt_renderer_create: hipStreamCreate failed"); return fail(RT_ERR_DEVICE); }
@@ -993,21 +1075,41 @@ static int render_light(rt_renderer* r, uint32_t batch, uint64_t seed, uint64_t 
     return RT_OK;
 }
 
+static int render_mlt(rt_renderer* r, uint32_t chains, uint64_t seed, uint64_t first_sample) {
+    const DScene& S = r->scene->d;
+    RBuf& R = r->R;
+    const uint32_t n = chains * RT_MLT_PATHS;
+    LAUNCHK(RT_KID_GENERATE, k_mlt_generate, r->flat_blocks, 256, S, R, n, chains, seed, first_sample);
+    for (int b = 0; b < RT_MAX_DEPTH + 2; b++) {
+        int cur = b & 1;
+        LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n, n);
+        LAUNCHK(RT_KID_EXTEND, (k_extend<false, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
+        LAUNCH(k_bin, r->flat_blocks / 2, RT_BIN_BLOCK, R, r->ctl, cur, b == 0 ? 1 : 0);
+        LAUNCHK(RT_KID_SHADE, k_shade<false>, r->flat_blocks / 2, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
+        LAUNCHK(RT_KID_CONNECT, k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
+    }
+    LAUNCH(k_ctl_final, 1, 1, r->ctl);
+    LAUNCHK(RT_KID_ACCUMULATE, k_mlt_chain, (chains + 63) / 64, 64, S, R, r->film, chains, seed, first_sample);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
 extern "C" int rt_render(rt_renderer* r, int mode, int spp, uint64_t seed, uint64_t first_sample) {
     if (!r || spp < 0) { rt_set_error("rt_render: bad argument"); return RT_ERR_INVALID; }
     if (mode == RT_MODE_PATH_ST) mode = RT_MODE_PATH;
-    if (mode == RT_MODE_MLT) { rt_set_error("rt_render: RT_MODE_MLT (PSSMLT) is not implemented in this round"); return RT_ERR_UNSUPPORTED; }
-    if (mode != RT_MODE_PATH && mode != RT_MODE_LIGHT && mode != RT_MODE_RADIOSITY && mode != RT_MODE_AOV_ALBEDO && mode != RT_MODE_AOV_NORMAL &&
+    if (mode != RT_MODE_PATH && mode != RT_MODE_LIGHT && mode != RT_MODE_MLT && mode != RT_MODE_RADIOSITY && mode != RT_MODE_AOV_ALBEDO && mode != RT_MODE_AOV_NORMAL &&
         mode != RT_MODE_DIRECT) { rt_set_error("rt_render: unknown mode"); return RT_ERR_INVALID; }
     RT_HIP(hipSetDevice(r->scene->device));
     r->count_enabled = r->scene->count_enabled;  // node/triangle fetch counting (atomics) follows rt_counters_enable
     uint32_t bmax = r->batch_max;
     if (mode == RT_MODE_LIGHT) bmax = std::max<uint32_t>(1, r->R.cap / ((uint32_t)r->W * r->H));
+    if (mode == RT_MODE_MLT) bmax = std::max<uint32_t>(1, r->R.cap / RT_MLT_PATHS);  // one chain per spp, all chains of a batch side by side
     int done = 0;
     while (done < spp) {
         uint32_t b = std::min<uint32_t>(bmax, (uint32_t)(spp - done));
         int rc;
         if (mode == RT_MODE_LIGHT) rc = render_light(r, b, seed, first_sample + done);
+        else if (mode == RT_MODE_MLT) rc = render_mlt(r, b, seed, first_sample + done);
         else if (mode == RT_MODE_AOV_ALBEDO || mode == RT_MODE_AOV_NORMAL || mode == RT_MODE_DIRECT) rc = render_aov(r, mode, b, seed, first_sample + done);
         else rc = render_path_like(r, mode, b, seed, first_sample + done);
         if (rc) return rc;

@@ -75,3 +75,18 @@ def test_oracle_vs_live_reference_build():
         for i in (0, s.ntris // 3, s.ntris - 1):
             assert (bits(o.tri_derived(i)) == bits(r.tri_derived(i))).all()
         r.close()
+
+
+def test_oracle_pssmlt_is_deterministic_and_covers_the_film():
+    """PSSMLT restatement (Renderer.h:964-1063): parity unpinned (Renderer.h needs the Windows window header, so upstream's
+    own PSSMLT cannot be built here); this pins the restatement's stated behaviour: same seed -> same film, disjoint
+    sample indices -> different chains, proposals land uniformly over the film (every proposal's (x, y) is a fresh draw)."""
+    from raytracer_amd import scenes
+    o = orc.OracleScene(scenes.cornell(32, 32))
+    a = o.mlt_render(1, seed=3)
+    b = o.mlt_render(1, seed=3)
+    c = o.mlt_render(1, seed=3, first_sample=1)
+    assert np.isfinite(a).all() and np.array_equal(a, b) and not np.array_equal(a, c)
+    assert (a.sum(-1) > 0).mean() > 0.6          # 100 000 proposals over 1024 pixels: only black pixels stay empty
+    both = o.mlt_render(2, seed=3)
+    assert np.allclose(both, a + c, rtol=1e-3, atol=1e-2)   # same splats, different fp32 summation order

@@ -112,6 +112,26 @@ def test_light_tracing_same_seed():
     assert abs(cnt["any_rays"] / st["any_rays"] - 1) < 2e-3
 
 
+def test_pssmlt_same_seed():
+    """renderSTMLT (Renderer.h:353, :1013): one chain of 100 000 proposals per spp; same numbers on both sides.  A chain can
+    only part from the oracle's where an acceptance draw falls within rounding of a, and it rejoins at the next proposal
+    both accept (proposals do not depend on the chain state), so the films agree like the other same-seed renders."""
+    s = scenes.cornell(64, 64)
+    want = orc.OracleScene(s).mlt_render(3, seed=11)
+    got, cnt = gpu_render(s, api.MLT, 3, seed=11)
+    assert np.isfinite(got).all() and got.sum() > 0
+    assert abs(got.sum() / want.sum() - 1) < 5e-3
+    f = lambda a: a.reshape(16, 4, 16, 4, 3).sum((1, 3))   # splats are sparse: compare a 4x4 box-filtered film
+    assert rel_mse(f(got), f(want), eps=1.0) < 1e-3
+    assert cnt["closest_rays"] > 3 * 100101
+    # spp split across calls / sample offsets composes (one chain per sample index)
+    sc = api.Scene(s)
+    a = api.RayTracer(sc); a.render(api.MLT, 1, 11, 0); a.render(api.MLT, 2, 11, 1)
+    fa, n = a.film()
+    assert n == 3 and np.allclose(fa, got, rtol=1e-4, atol=1e-5)
+    a.close(); sc.close()
+
+
 def test_instant_radiosity_same_seed():
     s = scenes.cornell(64, 64)
     o = orc.OracleScene(s)
