@@ -8,12 +8,16 @@ HDRS = $(wildcard $(CSRC)/*.h) include/rtamd.h
 # -fno-slp-vectorize: the SLP vectorizer packs the triangle test into v_pk_* ops glued by ~35 v_movs; measured 4 % slower
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -Wall -Wno-unused-function
 
-all: product oracle
+all: product oracle host
+# C++ host mirror + headless driver (links the C ABI only; no HIP code on this side)
+host: raytracer_amd/host/rtamd_cli
+raytracer_amd/host/rtamd_cli: raytracer_amd/host/main.cpp raytracer_amd/host/rtamd.hpp include/rtamd.h raytracer_amd/librtamd.so
+	g++ -std=c++17 -O2 -Wall -Wextra raytracer_amd/host/main.cpp -o $@ -Lraytracer_amd -lrtamd -Wl,-rpath,'$$ORIGIN/..'
 product: raytracer_amd/librtamd.so
 raytracer_amd/librtamd.so: $(SRCS) $(HDRS)
 	$(HIPCC) $(HIPFLAGS) $(SRCS) -o $@
 oracle:
 	$(MAKE) -C oracle
 clean:
-	rm -f raytracer_amd/librtamd.so oracle/liboracle.so
-.PHONY: all product oracle clean
+	rm -f raytracer_amd/librtamd.so oracle/liboracle.so raytracer_amd/host/rtamd_cli
+.PHONY: all product oracle host clean

@@ -91,3 +91,27 @@ class Marshalled:
         d.n_textures = self.n_tex
         d.background = self.bg
         return d
+
+
+RTSC_MAGIC = 0x43535452  # "RTSC"
+
+
+def save_rtsc(s: SceneData, path: str) -> None:
+    """Flat little-endian scene file read by the C++ host driver (raytracer_amd/host/rtamd.hpp loadScene):
+    header {magic, version=1, n_tris, n_materials, n_textures, width, height, P[16], V[16], bg_kind, bg_colour[3], bg_env_tex},
+    rt_material[n_materials], per texture {w, h, has_alpha, rgb[w*h*3]}, tri_material[n_tris], verts[n_tris*24]."""
+    m = Marshalled(s)
+    with open(path, "wb") as f:
+        f.write(np.array([RTSC_MAGIC, 1, m.n_tris, m.n_mats, m.n_tex], np.uint32).tobytes())
+        f.write(np.array([s.width, s.height], np.int32).tobytes())
+        f.write(np.asarray(s.cam_P, np.float32).tobytes())
+        f.write(np.asarray(s.cam_V, np.float32).tobytes())
+        f.write(np.array([s.bg_kind], np.uint32).tobytes())
+        f.write(np.asarray(s.bg_colour, np.float32).tobytes())
+        f.write(np.array([s.bg_env_tex], np.int32).tobytes())
+        f.write(bytes(m.mats)[: 64 * m.n_mats])
+        for t in m.tex_data:
+            f.write(np.array([t.shape[1], t.shape[0], 0], np.int32).tobytes())
+            f.write(t.tobytes())
+        f.write(m.tri_mat.tobytes())
+        f.write(m.verts.tobytes())

@@ -1,0 +1,68 @@
+// Headless counterpart of RTBase's Main.cpp: same arguments (-scene, -outputFilename, -SPP; Main.cpp:56-70), same loop
+// (render() until getSPP() == SPP, print the seconds each call took, then saveHDR; Main.cpp:79-137), no window.
+// Extra arguments: -type (RayTracer::type, Renderer.h:372), -width/-height (built-in cornell-box only), -seed,
+// -sppPerCall (samples added per render() call), -vpls (traceVPLs before type 4), -png (also write the tonemapped PNG).
+#include <chrono>
+#include <iostream>
+#include <unordered_map>
+
+#include "rtamd.hpp"
+
+int main(int argc, char* argv[]) {
+    std::string sceneName = "cornell-box";
+    std::string filename = "radiosity.hdr";   // upstream's default name (Main.cpp:29)
+    unsigned int SPP = 8192;
+    int type = 0, width = 1024, height = 1024, perCall = 1, vpls = 0, png = 0;
+    unsigned long long seed = 1;
+    std::unordered_map<std::string, std::string> args;
+    for (int i = 1; i < argc; ++i) {
+        std::string arg = argv[i];
+        if (!arg.empty() && arg[0] == '-') {
+            if (i + 1 < argc) args[arg] = argv[++i];
+            else std::cerr << "Error: Missing value for argument '" << arg << "'\n";
+        } else std::cerr << "Warning: Ignoring unexpected argument '" << arg << "'\n";
+    }
+    try {
+        for (const auto& pair : args) {
+            if (pair.first == "-scene") sceneName = pair.second;
+            else if (pair.first == "-outputFilename") filename = pair.second;
+            else if (pair.first == "-SPP") SPP = (unsigned int)std::stoi(pair.second);
+            else if (pair.first == "-type") type = std::stoi(pair.second);
+            else if (pair.first == "-width") width = std::stoi(pair.second);
+            else if (pair.first == "-height") height = std::stoi(pair.second);
+            else if (pair.first == "-seed") seed = std::stoull(pair.second);
+            else if (pair.first == "-sppPerCall") perCall = std::stoi(pair.second);
+            else if (pair.first == "-vpls") vpls = std::stoi(pair.second);
+            else if (pair.first == "-png") png = std::stoi(pair.second);
+            else std::cerr << "Warning: unknown argument '" << pair.first << "'\n";
+        }
+        if (perCall < 1) perCall = 1;
+        rtamd::Scene* scene = rtamd::loadScene(sceneName, width, height);
+        rt_scene_info info = scene->info();
+        std::cout << "number of triangle: " << info.n_tris << "\n";   // Scene::build prints this (Scene.h:101)
+        {
+        rtamd::RayTracer rt;
+        rt.init(scene);
+        rt.type = type;
+        rt.seed = seed;
+        if (vpls > 0) rt.traceVPLs(vpls);
+        while ((unsigned int)rt.getSPP() < SPP) {
+            rt.samplesPerCall = (int)std::min<unsigned int>((unsigned int)perCall, SPP - (unsigned int)rt.getSPP());
+            auto t0 = std::chrono::steady_clock::now();
+            rt.render();
+            rt.sync();
+            std::cout << std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count() << std::endl;   // Main.cpp:122
+        }
+        rt.saveHDR(filename);   // Main.cpp:133-136
+        if (png) {
+            size_t pos = filename.find_last_of('.');
+            rt.savePNG(filename.substr(0, pos) + ".png");   // Main.cpp:129-131
+        }
+        }   // the renderer goes before its scene
+        delete scene;
+    } catch (const std::exception& e) {
+        std::cerr << "rtamd: " << e.what() << "\n";
+        return 1;
+    }
+    return 0;
+}
