@@ -268,6 +268,34 @@ def cornell(width=1024, height=1024, with_specular=False):
     return set_camera(s, (0, 1.0, 4.4), (0, 1.0, 0), (0, 1, 0), 40.0, width, height)
 
 
+def open_box(width=96, height=96, background="env"):
+    """Cornell box without ceiling or light under a sky: `background` "env" = lat-long EnvironmentMap (Lights.h:138),
+    "colour" = BackgroundColour (Lights.h:87).  Exercises the non-area branch of computeDirect (Renderer.h:186-199) and
+    the un-weighted background term of pathTrace (Renderer.h:254)."""
+    b = _Builder()
+    rng = np.random.default_rng(5)
+    tex = [solid((0.73, 0.73, 0.73)), solid((0.65, 0.05, 0.05)), solid((0.12, 0.45, 0.15))]
+    mats = [Material(DIFFUSE, 0), Material(DIFFUSE, 1), Material(DIFFUSE, 2)]
+    W, Hh = 1.0, 2.0
+    b.add(*quad_grid((-W, 0, W), (2 * W, 0, 0), (0, 0, -2 * W), 1, 1, (0, 1, 0)), 0)
+    b.add(*quad_grid((-W, 0, -W), (2 * W, 0, 0), (0, Hh, 0), 1, 1, (0, 0, 1)), 0)
+    b.add(*quad_grid((-W, 0, W), (0, 0, -2 * W), (0, Hh, 0), 1, 1, (1, 0, 0)), 1)
+    b.add(*quad_grid((W, 0, -W), (0, 0, 2 * W), (0, Hh, 0), 1, 1, (-1, 0, 0)), 2)
+    b.add(*box((-0.3, 0.0, -0.3), (0.3, 0.7, 0.3), rot_y=0.4), 0)
+    v, m = b.finish()
+    s = SceneData("open-box-" + background, v, m, mats, tex)
+    if background == "env":
+        yy, xx = np.meshgrid(np.linspace(0, 1, 32, dtype=np.float32), np.linspace(0, 1, 64, dtype=np.float32), indexing="ij")
+        sky = np.stack([0.4 + 0.6 * (1 - yy), 0.5 + 0.5 * (1 - yy), 0.9 + 0 * yy], -1).astype(np.float32)
+        sky += (8.0 * np.exp(-((xx - 0.3) ** 2 + (yy - 0.25) ** 2) / 0.004))[..., None].astype(np.float32)   # a sun
+        sky += rng.uniform(0, 0.05, sky.shape).astype(np.float32)
+        s.textures.append(np.ascontiguousarray(sky))
+        s.bg_kind, s.bg_env_tex = 1, len(s.textures) - 1
+    else:
+        s.bg_kind, s.bg_colour = 0, (0.9, 1.0, 1.3)
+    return set_camera(s, (0, 1.0, 4.4), (0, 0.8, 0), (0, 1, 0), 40.0, width, height)
+
+
 def interior(variant="bathroom", detail=1.0, width=1920, height=1080, seed=1, conductor=False):
     """Closed-room stand-in for the bathroom / living-room scenes: ~1.0 M triangles at detail=1
     (triangle count scales ~detail^2), tessellated displaced fixtures, thin slats (blinds), glass bulbs,
