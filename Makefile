@@ -11,8 +11,8 @@ HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-slp-vect
 all: product oracle host
 # C++ host mirror + headless driver (links the C ABI only; no HIP code on this side)
 host: raytracer_amd/host/rtamd_cli
-raytracer_amd/host/rtamd_cli: raytracer_amd/host/main.cpp raytracer_amd/host/rtamd.hpp include/rtamd.h raytracer_amd/librtamd.so
-	g++ -std=c++17 -O2 -Wall -Wextra raytracer_amd/host/main.cpp -o $@ -Lraytracer_amd -lrtamd -Wl,-rpath,'$$ORIGIN/..'
+raytracer_amd/host/rtamd_cli: raytracer_amd/host/main.cpp raytracer_amd/host/rtamd.hpp raytracer_amd/host/gem.hpp include/rtamd.h raytracer_amd/librtamd.so
+	g++ -std=c++17 -O2 -ffp-contract=off -Wall -Wextra raytracer_amd/host/main.cpp -o $@ -Lraytracer_amd -lrtamd -Wl,-rpath,'$$ORIGIN/..'
 product: raytracer_amd/librtamd.so
 raytracer_amd/librtamd.so: $(SRCS) $(HDRS)
 	$(HIPCC) $(HIPFLAGS) $(SRCS) -o $@

@@ -118,6 +118,11 @@ int rt_scene_leaf_order(const rt_scene* scene, uint32_t* out_n_tris);
  * Not a compute path: nothing can be traversed or rendered without a GPU. */
 int rt_host_build_info(const rt_scene_desc* desc, uint32_t* leaf_order, rt_scene_info* info);
 
+/* Matrix::invert (Core.h:326, the unrolled MESA inverse in fp32): host utility, row-major 4x4, no device involved.
+ * The library uses the same routine for the camera's inverse matrices; loaders use it for V = lookAt().invert()
+ * (SceneLoader.h:252) and the instance normal matrix (SceneLoader.h:199). */
+int rt_matrix_invert(const float* m16, float* out16);
+
 /* --- IntersectionData Scene::traverse(const Ray&) (Scene.h:118), batched.
  * `mode`: 0 = 4-wide ordered walk (+ reference-order fallback for rays with a zero/denormal
  * direction component), 1 = reference-order walk for every ray (validation).

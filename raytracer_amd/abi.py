@@ -115,3 +115,26 @@ def save_rtsc(s: SceneData, path: str) -> None:
             f.write(t.tobytes())
         f.write(m.tri_mat.tobytes())
         f.write(m.verts.tobytes())
+
+
+def load_rtsc(path: str) -> SceneData:
+    """Reader for save_rtsc / the C++ host's saveRTSC (materials come back as abi.Material structs)."""
+    b = open(path, "rb").read()
+    magic, ver, nt, nm, ntex = np.frombuffer(b, np.uint32, 5, 0)
+    assert magic == RTSC_MAGIC and ver == 1
+    w, h = np.frombuffer(b, np.int32, 2, 20)
+    o = 28
+    P = np.frombuffer(b, np.float32, 16, o).copy(); o += 64
+    V = np.frombuffer(b, np.float32, 16, o).copy(); o += 64
+    bg_kind = int(np.frombuffer(b, np.uint32, 1, o)[0]); o += 4
+    bg_colour = tuple(float(x) for x in np.frombuffer(b, np.float32, 3, o)); o += 12
+    bg_env = int(np.frombuffer(b, np.int32, 1, o)[0]); o += 4
+    mats = [Material.from_buffer_copy(b, o + 64 * i) for i in range(nm)]; o += 64 * int(nm)
+    tex = []
+    for _ in range(ntex):
+        tw, th, _a = np.frombuffer(b, np.int32, 3, o); o += 12
+        tex.append(np.frombuffer(b, np.float32, int(tw) * int(th) * 3, o).reshape(int(th), int(tw), 3).copy()); o += int(tw) * int(th) * 12
+    tm = np.frombuffer(b, np.uint32, int(nt), o).copy(); o += 4 * int(nt)
+    verts = np.frombuffer(b, np.float32, int(nt) * 24, o).reshape(int(nt), 3, 8).copy(); o += 96 * int(nt)
+    assert o == len(b)
+    return SceneData("rtsc", verts, tm, mats, tex, bg_kind, bg_colour, bg_env, P, V, int(w), int(h))

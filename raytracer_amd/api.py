@@ -53,7 +53,7 @@ SYMBOLS = [
     "rt_intersect_any", "rt_intersect_any_dev", "rt_generate_rays", "rt_counters_enable", "rt_counters_read",
     "rt_renderer_create", "rt_renderer_destroy", "rt_render", "rt_film_clear", "rt_film_spp", "rt_film_read", "rt_film_bind",
     "rt_film_set_spp", "rt_vpl_trace", "rt_vpl_count", "rt_render_counters", "rt_renderer_sync", "rt_film_save_hdr",
-    "rt_film_tonemap", "rt_profile_enable", "rt_profile_read", "rt_debug_bsdf_sample", "rt_debug_bsdf_eval", "rt_debug_rng",
+    "rt_film_tonemap", "rt_profile_enable", "rt_profile_read", "rt_debug_bsdf_sample", "rt_debug_bsdf_eval", "rt_debug_rng", "rt_matrix_invert",
 ]
 
 

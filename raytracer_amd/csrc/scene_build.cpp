@@ -416,6 +416,13 @@ F3 mul_vec(const float* m, F3 v) {
 }
 }  // namespace
 
+// Matrix::invert (Core.h:326) for host code above the ABI (lookAt().invert(), instance normal matrices)
+extern "C" int rt_matrix_invert(const float* m16, float* out16) {
+    if (!m16 || !out16) return -1;
+    invert4(m16, out16);
+    return 0;
+}
+
 void host_camera_build(const rt_camera& c, DCamera& o) {
     memcpy(o.P, c.P, 64);
     invert4(c.P, o.invP);

@@ -1,18 +1,20 @@
 // Headless counterpart of RTBase's Main.cpp: same arguments (-scene, -outputFilename, -SPP; Main.cpp:56-70), same loop
 // (render() until getSPP() == SPP, print the seconds each call took, then saveHDR; Main.cpp:79-137), no window.
 // Extra arguments: -type (RayTracer::type, Renderer.h:372), -width/-height (built-in cornell-box only), -seed,
-// -sppPerCall (samples added per render() call), -vpls (traceVPLs before type 4), -png (also write the tonemapped PNG).
+// -sppPerCall (samples added per render() call), -vpls (traceVPLs before type 4), -png (also write the tonemapped PNG),
+// -dump file.rtsc (load the scene, write it as a flat file and stop: checks the loaders without a GPU).
 #include <chrono>
 #include <iostream>
 #include <unordered_map>
 
-#include "rtamd.hpp"
+#include "gem.hpp"
 
 int main(int argc, char* argv[]) {
     std::string sceneName = "cornell-box";
     std::string filename = "radiosity.hdr";   // upstream's default name (Main.cpp:29)
     unsigned int SPP = 8192;
     int type = 0, width = 1024, height = 1024, perCall = 1, vpls = 0, png = 0;
+    std::string dump;
     unsigned long long seed = 1;
     std::unordered_map<std::string, std::string> args;
     for (int i = 1; i < argc; ++i) {
@@ -34,9 +36,17 @@ int main(int argc, char* argv[]) {
             else if (pair.first == "-sppPerCall") perCall = std::stoi(pair.second);
             else if (pair.first == "-vpls") vpls = std::stoi(pair.second);
             else if (pair.first == "-png") png = std::stoi(pair.second);
+            else if (pair.first == "-dump") dump = pair.second;
             else std::cerr << "Warning: unknown argument '" << pair.first << "'\n";
         }
         if (perCall < 1) perCall = 1;
+        if (!dump.empty()) {   // loader check: parse the scene and write it back as a flat RTSC file; no device involved
+            rtamd::Scene* host = rtamd::loadScene(sceneName, width, height, false);
+            rtamd::saveRTSC(*host, dump);
+            std::cout << "number of triangle: " << host->triangles.size() << "\n";
+            delete host;
+            return 0;
+        }
         rtamd::Scene* scene = rtamd::loadScene(sceneName, width, height);
         rt_scene_info info = scene->info();
         std::cout << "number of triangle: " << info.n_tris << "\n";   // Scene::build prints this (Scene.h:101)

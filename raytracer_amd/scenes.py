@@ -50,6 +50,7 @@ class SceneData:
     cam_V: np.ndarray = field(default=None)   # camera-to-world
     width: int = 0
     height: int = 0
+    cam_params: dict = field(default=None)    # from / to / up / fov / flip_x as given to set_camera (scene.json properties)
 
     @property
     def ntris(self) -> int:
@@ -93,6 +94,7 @@ def set_camera(scene: SceneData, frm, to, up, fov, width, height, flip_x=False):
     V = look_at(frm, to, up).reshape(4, 4).astype(np.float64)
     V = np.linalg.inv(V).astype(np.float32).reshape(16)  # V = lookAt().invert() (SceneLoader.h:251-252)
     scene.cam_P, scene.cam_V, scene.width, scene.height = P, V, int(width), int(height)
+    scene.cam_params = dict(frm=tuple(map(float, frm)), to=tuple(map(float, to)), up=tuple(map(float, up)), fov=float(fov), flip_x=bool(flip_x))
     return scene
 
 
