@@ -72,6 +72,9 @@ def main():
     if Wm > 0:
         rt.render(api.PATH, Wm, seed, base)
     rt.sync()
+    if world > 1:
+        dist.all_reduce(film)  # warm-up of the film reduction too: RCCL sets up its channels / buffers on the first call of a size
+        torch.cuda.synchronize()
     rt.clear()
     rt.counters(reset=True)
     rt.profile_enable(True)
