@@ -53,7 +53,7 @@ SYMBOLS = [
     "rt_intersect_any", "rt_intersect_any_dev", "rt_generate_rays", "rt_counters_enable", "rt_counters_read",
     "rt_renderer_create", "rt_renderer_destroy", "rt_render", "rt_film_clear", "rt_film_spp", "rt_film_read", "rt_film_bind",
     "rt_film_set_spp", "rt_vpl_trace", "rt_vpl_count", "rt_render_counters", "rt_renderer_sync", "rt_film_save_hdr",
-    "rt_film_tonemap", "rt_profile_enable", "rt_profile_read", "rt_debug_bsdf_sample", "rt_debug_bsdf_eval", "rt_debug_rng", "rt_matrix_invert",
+    "rt_film_tonemap", "rt_profile_enable", "rt_profile_read", "rt_debug_bsdf_sample", "rt_debug_bsdf_eval", "rt_debug_rng", "rt_matrix_invert", "rt_scene_create_ex",
 ]
 
 
@@ -80,6 +80,7 @@ def lib():
         _sig(L, "rt_last_error", None, C.c_char_p, True)
         vp, sz, i32, u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64
         _sig(L, "rt_scene_create", [C.POINTER(SceneDesc), C.POINTER(vp)])
+        _sig(L, "rt_scene_create_ex", [C.POINTER(SceneDesc), C.c_uint32, C.POINTER(vp)])
         _sig(L, "rt_scene_destroy", [vp])
         _sig(L, "rt_scene_destroy", None, None, True)
         _sig(L, "rt_scene_set_camera", [vp, C.POINTER(Camera)])
@@ -145,13 +146,13 @@ def rng_floats(seed, sample, pixel, stream, n):
 class Scene:
     """Scene::init + Scene::build on the GPU (Scene.h:150, :92)."""
 
-    def __init__(self, s: SceneData):
+    def __init__(self, s: SceneData, device_build: bool = False):
         self.L = lib()
         self.data = s
         self.m = Marshalled(s)
         d = self.m.desc()
         h = C.c_void_p()
-        _check(self.L.rt_scene_create(C.byref(d), C.byref(h)), "rt_scene_create")
+        _check(self.L.rt_scene_create_ex(C.byref(d), C.c_uint32(1 if device_build else 0), C.byref(h)), "rt_scene_create")
         self.h = h
         self.width, self.height, self.ntris = s.width, s.height, s.ntris
         if s.cam_P is not None:

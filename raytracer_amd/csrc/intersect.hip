@@ -152,8 +152,13 @@ static int upload(rt_scene* s, const std::vector<T>& v, const T** dst) {
 
 int rt_scene_persistent_blocks(const rt_scene* s) { return s->persistent_blocks; }
 
-extern "C" int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
+bool device_bvh2_build(const float* h_verts, uint32_t n, Bvh2& out, std::string& err);   // bvh_build.hip
+
+extern "C" int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) { return rt_scene_create_ex(desc, 0u, out); }
+
+extern "C" int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_scene** out) {
     if (!desc || !out) { rt_set_error("rt_scene_create: NULL argument"); return RT_ERR_INVALID; }
+    if (flags & ~(uint32_t)RT_SCENE_BUILD_DEVICE) { rt_set_error("rt_scene_create_ex: unknown flag"); return RT_ERR_INVALID; }
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -162,7 +167,9 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
     }
     rt_scene* s = new rt_scene();
     std::string err;
-    if (!host_scene_build(*desc, s->host, err)) { rt_set_error("rt_scene_create: " + err); delete s; return RT_ERR_INVALID; }
+    if (!host_scene_build(*desc, s->host, err, (flags & RT_SCENE_BUILD_DEVICE) ? device_bvh2_build : nullptr)) {
+        rt_set_error("rt_scene_create: " + err); delete s; return RT_ERR_INVALID;
+    }
     int rc = RT_OK;
     auto fail = [&](int code) { rt_scene_destroy(s); return code; };
     if (hipGetDevice(&s->device) != hipSuccess) return fail(RT_ERR_DEVICE);

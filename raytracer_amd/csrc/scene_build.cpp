@@ -243,7 +243,7 @@ inline float lum(const float* c) { return ((0.2126f * c[0]) + (0.7152f * c[1]) +
 
 }  // namespace
 
-bool host_scene_build(const rt_scene_desc& d, HostScene& hs, std::string& err) {
+bool host_scene_build(const rt_scene_desc& d, HostScene& hs, std::string& err, Bvh2Builder device_builder) {
     auto t0 = std::chrono::steady_clock::now();
     if (d.n_tris > RT_LEAF_FIRST_MASK) { err = "too many triangles (max 2^27-1)"; return false; }
     if (d.n_tris && (!d.verts || !d.tri_material)) { err = "verts/tri_material is NULL"; return false; }
@@ -288,7 +288,21 @@ bool host_scene_build(const rt_scene_desc& d, HostScene& hs, std::string& err) {
 
     // reference tree
     Builder b; b.verts = d.verts; b.n = d.n_tris;
-    b.build();
+    if (device_builder && d.n_tris > 0) {
+        Bvh2 t;
+        if (!device_builder(d.verts, d.n_tris, t, err)) return false;
+        b.order.swap(t.order);
+        b.nodes.resize(t.nodes.size());
+        for (size_t i = 0; i < t.nodes.size(); i++) {
+            const Bvh2Node& s = t.nodes[i];
+            BNode& o = b.nodes[i];
+            o.box.lo = f3(s.lo[0], s.lo[1], s.lo[2]); o.box.hi = f3(s.hi[0], s.hi[1], s.hi[2]);
+            o.left = s.left; o.right = s.right; o.begin = s.begin; o.count = s.count; o.depth = s.depth;
+            b.max_depth = std::max(b.max_depth, s.depth);
+            if (s.left < 0) { o.first = s.begin; o.nleaf = s.count; b.leaves++; b.max_leaf = std::max(b.max_leaf, s.count); }
+        }
+    } else b.build();
+    if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "bvh2 build %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     hs.leaf_order = b.order;
     hs.depth2 = b.max_depth; hs.leaves2 = b.leaves; hs.max_leaf2 = b.max_leaf;
     hs.max_stack2 = b.max_depth + 2;
@@ -355,6 +369,7 @@ bool host_scene_build(const rt_scene_desc& d, HostScene& hs, std::string& err) {
         if (hs.nodes4.size() > (1u << 25)) { err = "wide BVH exceeds 2^25 nodes (32-bit node offsets)"; return false; }
     }
 
+    if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "records + collapse done at %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     // light list: background first if it has power (Scene.h:164), then emissive triangles in caller order (Scene.h:107)
     {
         float power = 0;

@@ -28,7 +28,15 @@ struct HostScene {
     double build_seconds = 0;
 };
 
-// Returns false and fills `err` on invalid input.
-bool host_scene_build(const rt_scene_desc& d, HostScene& out, std::string& err);
+// The reference-topology binary tree as a builder hands it over: node 0 is the root, leaves have left == right == -1,
+// [begin, begin + count) is the node's range in `order` (= DFS leaf order: the partitions keep the left child first).
+// Nodes with count <= 1 keep the inverted default box (Geometry.h:401 returns before the bounds are grown).
+struct Bvh2Node { float lo[3], hi[3]; int32_t left, right; uint32_t begin, count, depth; };
+struct Bvh2 { std::vector<Bvh2Node> nodes; std::vector<uint32_t> order; };
+typedef bool (*Bvh2Builder)(const float* verts, uint32_t n_tris, Bvh2& out, std::string& err);
+
+// Returns false and fills `err` on invalid input.  `device_builder` (bvh_build.hip) replaces the host's own
+// binned-SAH build of the binary tree when given; everything downstream is the same code.
+bool host_scene_build(const rt_scene_desc& d, HostScene& out, std::string& err, Bvh2Builder device_builder = nullptr);
 // Camera::init + Camera::updateView (Scene.h:26-45)
 void host_camera_build(const rt_camera& c, DCamera& out);
