@@ -81,21 +81,22 @@ def test_edge_cases():
         so.close()
 
 
-def test_full_size_wide_walk_equals_reference_order_walk():
-    """At the bench's full size the oracle is too slow; the size-independent property is that the ordered,
-    culled 4-wide walk returns exactly what the reference-order walk (pinned above) returns."""
-    s = scenes.bathroom(1.0, 1920, 1080)
-    sc = api.Scene(s)
+@pytest.mark.parametrize("make,label", [(scenes.bathroom, "bathroom"), (scenes.living_room, "living-room")])
+def test_full_size_wide_walk_equals_reference_order_walk(make, label):
+    """At the bench's full size (BASELINE configs 3-4) the oracle is too slow; the size-independent property is that the
+    ordered, culled 4-wide walk returns exactly what the reference-order walk (pinned above) returns."""
+    s = make(1.0, 1920, 1080)
+    sc = api.Scene(s, device_build=(label == "living-room"))
     info = sc.info()
     assert info["n_tris"] > 500_000
     n = 1 << 20
     rays = np.concatenate([scenes.primary_rays(s, n, 1), scenes.bounce_rays(s, n, 2)])
     a, b = sc.traverse(rays, 0), sc.traverse(rays, 1)
-    assert_hits_bitexact(a, b, "bathroom full size")
+    assert_hits_bitexact(a, b, label + " full size")
     segs = scenes.shadow_segments(s, n, 3)
     assert (sc.visible(segs, 0) == sc.visible(segs, 1)).all()
     # spot-check a slice against the CPU oracle as well
     o = orc.OracleScene(s)
     idx = np.random.default_rng(1).integers(0, len(rays), 20_000)
-    assert_hits_bitexact(a[idx], o.traverse(rays[idx], threads=16), "bathroom oracle slice")
+    assert_hits_bitexact(a[idx], o.traverse(rays[idx], threads=16), label + " oracle slice")
     sc.close()

@@ -70,6 +70,23 @@ def test_batching_and_sample_offsets_compose():
     sc.close()
 
 
+def test_4k_render_sample_partition_composes():
+    """BASELINE config 4 shape: bathroom at 3840x2160 (2 spp per batch).  Size-independent properties: two "ranks" with disjoint
+    sample ranges sum to the single-renderer film, the film is finite where the frame has no specular fireflies, and
+    the ray count per pixel-sample is the 1080p figure."""
+    s = scenes.bathroom(0.5, 3840, 2160)
+    sc = api.Scene(s, device_build=True)
+    a = api.RayTracer(sc); a.render(api.PATH, 3, 5, 0); fa, _ = a.film(); ca = a.counters()
+    b = api.RayTracer(sc); b.render(api.PATH, 2, 5, 0); fb, _ = b.film(); b.close()
+    c = api.RayTracer(sc); c.render(api.PATH, 1, 5, 2); fc, _ = c.film(); c.close()
+    fin = np.isfinite(fa)
+    assert fin.mean() > 0.9999 and np.array_equal(fin, np.isfinite(fb + fc))
+    assert np.allclose(fa[fin], (fb + fc)[fin], rtol=1e-5, atol=1e-6)
+    rays_per_sample = (ca["closest_rays"] + ca["any_rays"]) / (3840 * 2160 * 3)
+    assert 4.0 < rays_per_sample < 7.5
+    a.close(); sc.close()
+
+
 def test_converged_render_relmse():
     """north_star image gate: 4096 spp vs the CPU render (independent seeds), relative MSE < 1e-3."""
     ref = np.load(os.path.join(GOLDEN, "film_cornell64_4096.npy"))
