@@ -95,6 +95,7 @@ typedef struct {
     uint64_t any_nodes_visited, any_tris_tested;  /* the same two counts for any-hit (Scene::visible) walks */
     uint64_t lane_slots, lane_busy;         /* closest-hit walks: 64 x wave traversal steps, and how many of those lanes held a ray */
     uint64_t any_lane_slots, any_lane_busy; /* the same for any-hit walks (SIMD lane occupancy = busy / slots) */
+    uint64_t max_steps, any_max_steps;      /* most wave steps any single ray stayed in flight (its share of a launch's tail) */
 } rt_counters;
 
 typedef struct rt_scene rt_scene;

@@ -38,7 +38,8 @@ class SceneInfo(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("closest_rays", C.c_uint64), ("any_rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
                 ("exact_path_rays", C.c_uint64), ("any_nodes_visited", C.c_uint64), ("any_tris_tested", C.c_uint64),
-                ("lane_slots", C.c_uint64), ("lane_busy", C.c_uint64), ("any_lane_slots", C.c_uint64), ("any_lane_busy", C.c_uint64)]
+                ("lane_slots", C.c_uint64), ("lane_busy", C.c_uint64), ("any_lane_slots", C.c_uint64), ("any_lane_busy", C.c_uint64),
+                ("max_steps", C.c_uint64), ("any_max_steps", C.c_uint64)]
 
     def asdict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

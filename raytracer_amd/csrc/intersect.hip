@@ -273,7 +273,7 @@ extern "C" int rt_counters_read(rt_scene* s, rt_counters* o, int reset) {
     RT_HIP(hipMemcpy(&c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     o->closest_rays = c.closest; o->any_rays = c.any; o->nodes_visited = c.nodes; o->tris_tested = c.tris; o->exact_path_rays = c.exact;
     o->any_nodes_visited = c.any_nodes; o->any_tris_tested = c.any_tris;
-    o->lane_slots = c.slots; o->lane_busy = c.busy; o->any_lane_slots = c.any_slots; o->any_lane_busy = c.any_busy;
+    o->lane_slots = c.slots; o->lane_busy = c.busy; o->any_lane_slots = c.any_slots; o->any_lane_busy = c.any_busy; o->max_steps = c.max_steps; o->any_max_steps = c.any_max_steps;
     if (reset) RT_HIP(hipMemset(s->d_counters, 0, sizeof(DCounters)));
     return RT_OK;
 }

@@ -919,6 +919,16 @@ struct rt_renderer {
     uint32_t* spill2 = nullptr;
     int trav_blocks = 0, flat_blocks = 0;
     int n_vpl = 0;
+    // Second lane: a full second set of wavefront state on its own stream.  rt_render alternates path-tracing batches
+    // between the two lanes, so the tail of one batch's persistent kernels (a launch lasts as long as its slowest ray:
+    // 0.6-2 ms of nearly idle GPU per k_extend launch on the bench scene) overlaps the other batch's work.  The active
+    // lane's state lives in the fields above; use_lane() swaps.
+    struct Lane { hipStream_t stream = nullptr; RBuf R{}; Ctl* ctl = nullptr; uint32_t* spill4 = nullptr; uint32_t* spill2 = nullptr; };
+    Lane other;
+    bool other_ready = false;
+    int active_lane = 0;
+    hipEvent_t acc_event = nullptr;   // film accumulation of the previous batch (keeps the fp32 sum order fixed)
+    bool acc_pending = false;
     bool count_enabled = false;
     std::vector<void*> allocs;
     // per-kernel HIP-event timing on the renderer's own stream (rt_profile_enable)
@@ -931,6 +941,18 @@ struct rt_renderer {
 };
 
 static void prof_collect(rt_renderer* r);
+static void use_lane(rt_renderer* r, int lane) {
+    if (r->active_lane == lane) return;
+    std::swap(r->stream, r->other.stream); std::swap(r->R, r->other.R); std::swap(r->ctl, r->other.ctl);
+    std::swap(r->spill4, r->other.spill4); std::swap(r->spill2, r->other.spill2);
+    r->active_lane = lane;
+}
+static hipError_t sync_all(rt_renderer* r) {
+    hipError_t e = hipStreamSynchronize(r->stream);
+    if (e == hipSuccess && r->other_ready) e = hipStreamSynchronize(r->other.stream);
+    if (e == hipSuccess) r->acc_pending = false;
+    return e;
+}
 
 template <class T>
 static int dev_alloc(rt_renderer* r, T** p, size_t count) {
@@ -944,10 +966,40 @@ static int dev_alloc(rt_renderer* r, T** p, size_t count) {
 
 extern "C" void rt_renderer_destroy(rt_renderer* r) {
     if (!r) return;
-    if (r->stream) { (void)hipStreamSynchronize(r->stream); prof_collect(r); (void)hipStreamDestroy(r->stream); }
+    if (r->stream) { (void)sync_all(r); prof_collect(r); (void)hipStreamDestroy(r->stream); }
+    if (r->other.stream) (void)hipStreamDestroy(r->other.stream);
+    if (r->acc_event) (void)hipEventDestroy(r->acc_event);
     for (hipEvent_t e : r->event_pool) (void)hipEventDestroy(e);
     for (void* p : r->allocs) (void)hipFree(p);
     delete r;
+}
+
+static int alloc_state(rt_renderer* r, RBuf& R, Ctl** ctl) {
+    int rc;
+    if ((rc = dev_alloc(r, &R.ray_o, R.cap)) || (rc = dev_alloc(r, &R.ray_d, R.cap)) || (rc = dev_alloc(r, &R.hit, R.cap)) ||
+        (rc = dev_alloc(r, &R.thr, R.cap)) || (rc = dev_alloc(r, &R.rad, R.cap)) || (rc = dev_alloc(r, &R.q_active[0], R.cap)) ||
+        (rc = dev_alloc(r, &R.q_active[1], R.cap)) || (rc = dev_alloc(r, &R.q_class, (size_t)R.cap * RT_NCLASS)) || (rc = dev_alloc(r, &R.cls, R.cap)) ||
+        (rc = dev_alloc(r, &R.shadow, (size_t)R.cap * 3)) || (rc = dev_alloc(r, ctl, 1)))
+        return rc;
+    return RT_OK;
+}
+// the second lane is only made when a render has two batches to overlap
+static int ensure_other_lane(rt_renderer* r) {
+    if (r->other_ready) return RT_OK;
+    rt_renderer::Lane& o = r->other;
+    const RBuf& A = r->active_lane == 0 ? r->R : r->other.R;
+    o.R = A;
+    o.R.gather = nullptr; o.R.vpl = nullptr; o.R.vpl_slots = 0;
+    int rc;
+    if (hipStreamCreate(&o.stream) != hipSuccess) { rt_set_error("rt_render: hipStreamCreate failed"); return RT_ERR_DEVICE; }
+    if ((rc = alloc_state(r, o.R, &o.ctl))) return rc;
+    size_t threads = (size_t)r->trav_blocks * RT_BLOCK;
+    const HostScene& h = r->scene->host;
+    if (h.max_stack4 > RT_STACK_LDS && (rc = dev_alloc(r, &o.spill4, threads * (h.max_stack4 - RT_STACK_LDS) * (RT_STACK_KEYS ? 2 : 1)))) return rc;
+    if ((rc = dev_alloc(r, &o.spill2, threads * std::max<uint32_t>(h.max_stack2, 2)))) return rc;
+    RT_HIP(hipMemsetAsync(o.ctl, 0, sizeof(Ctl), o.stream));
+    r->other_ready = true;
+    return RT_OK;
 }
 
 extern "C" int rt_renderer_create(rt_scene* scene, rt_renderer** out) {
@@ -962,18 +1014,21 @@ extern "C" int rt_renderer_create(rt_scene* scene, rt_renderer** out) {
     R.tiles_x = (R.w + 7) / 8;
     uint32_t tiles_y = (R.h + 7) / 8;
     R.np_pad = R.tiles_x * tiles_y * 64;
-    // batch: as many samples per pixel as fit ~16 M paths (about 3 GB of wavefront state; the card has 288 GB)
-    r->batch_max = std::max<uint32_t>(1, std::min<uint32_t>(64, (16u << 20) / R.np_pad));
+    // batch: as many samples per pixel as fit ~32 M paths per lane (about 5.3 GB of wavefront state each; the card has 288 GB)
+#ifndef RT_BATCH_PATHS
+#define RT_BATCH_PATHS (32u << 20)
+#endif
+#ifndef RT_LANES
+#define RT_LANES 2
+#endif
+    r->batch_max = std::max<uint32_t>(1, std::min<uint32_t>(64, RT_BATCH_PATHS / R.np_pad));
     R.cap = std::max<uint32_t>(R.np_pad * r->batch_max, (RT_MLT_PATHS + 63u) / 64u * 64u);  // room for at least one PSSMLT chain
     auto fail = [&](int rc) { rt_renderer_destroy(r); return rc; };
     int rc;
     if (hipStreamCreate(&r->stream) != hipSuccess) { rt_set_error("rt_renderer_create: hipStreamCreate failed"); return fail(RT_ERR_DEVICE); }
-    if ((rc = dev_alloc(r, &R.ray_o, R.cap)) || (rc = dev_alloc(r, &R.ray_d, R.cap)) || (rc = dev_alloc(r, &R.hit, R.cap)) ||
-        (rc = dev_alloc(r, &R.thr, R.cap)) || (rc = dev_alloc(r, &R.rad, R.cap)) || (rc = dev_alloc(r, &R.q_active[0], R.cap)) ||
-        (rc = dev_alloc(r, &R.q_active[1], R.cap)) || (rc = dev_alloc(r, &R.q_class, (size_t)R.cap * RT_NCLASS)) || (rc = dev_alloc(r, &R.cls, R.cap)) ||
-        (rc = dev_alloc(r, &R.shadow, (size_t)R.cap * 3)) || (rc = dev_alloc(r, &r->ctl, 1)) || (rc = dev_alloc(r, &r->counters, 1)) ||
-        (rc = dev_alloc(r, &r->film_own, (size_t)r->W * r->H * 3)))
+    if ((rc = alloc_state(r, R, &r->ctl)) || (rc = dev_alloc(r, &r->counters, 1)) || (rc = dev_alloc(r, &r->film_own, (size_t)r->W * r->H * 3)))
         return fail(rc);
+    if (hipEventCreateWithFlags(&r->acc_event, hipEventDisableTiming) != hipSuccess) { rt_set_error("rt_renderer_create: hipEventCreate failed"); return fail(RT_ERR_DEVICE); }
     R.gather = nullptr; R.vpl = nullptr; R.vpl_slots = 0;
     r->film = r->film_own;
     r->trav_blocks = scene->persistent_blocks;
@@ -1036,7 +1091,10 @@ static int render_path_like(rt_renderer* r, int mode, uint32_t batch, uint64_t s
         if (radiosity) LAUNCHK(RT_KID_GATHER, k_gather, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2);
     }
     LAUNCH(k_ctl_final, 1, 1, r->ctl);
+    if (r->acc_pending) RT_HIP(hipStreamWaitEvent(r->stream, r->acc_event, 0));   // film += in batch order, whichever lane ran the batch
     LAUNCHK(RT_KID_ACCUMULATE, k_accumulate, r->flat_blocks, 256, R, r->film, batch);
+    RT_HIP(hipEventRecord(r->acc_event, r->stream));
+    r->acc_pending = true;
     RT_HIP(hipGetLastError());
     return RT_OK;
 }
@@ -1105,6 +1163,21 @@ extern "C" int rt_render(rt_renderer* r, int mode, int spp, uint64_t seed, uint6
     if (mode == RT_MODE_LIGHT) bmax = std::max<uint32_t>(1, r->R.cap / ((uint32_t)r->W * r->H));
     if (mode == RT_MODE_MLT) bmax = std::max<uint32_t>(1, r->R.cap / RT_MLT_PATHS);  // one chain per spp, all chains of a batch side by side
     int done = 0;
+    if (mode == RT_MODE_PATH && spp >= 2 && RT_LANES > 1) {
+        // at least two batches, alternating between the two lanes (streams)
+        int rc = ensure_other_lane(r);
+        if (rc) return rc;
+        uint32_t nb = std::max<uint32_t>(2u, ((uint32_t)spp + bmax - 1) / bmax);
+        for (uint32_t i = 0; i < nb; i++) {
+            uint32_t b = (uint32_t)spp / nb + (i < (uint32_t)spp % nb ? 1u : 0u);
+            use_lane(r, (int)(i & 1u));
+            rc = render_path_like(r, mode, b, seed, first_sample + done);
+            if (rc) { use_lane(r, 0); return rc; }
+            done += (int)b;
+        }
+        use_lane(r, 0);
+        RT_HIP(hipStreamWaitEvent(r->stream, r->acc_event, 0));   // whatever is queued on lane 0 next sees the complete film
+    }
     while (done < spp) {
         uint32_t b = std::min<uint32_t>(bmax, (uint32_t)(spp - done));
         int rc;
@@ -1121,7 +1194,7 @@ extern "C" int rt_render(rt_renderer* r, int mode, int spp, uint64_t seed, uint6
 
 extern "C" int rt_renderer_sync(rt_renderer* r) {
     if (!r) { rt_set_error("rt_renderer_sync: NULL"); return RT_ERR_INVALID; }
-    RT_HIP(hipStreamSynchronize(r->stream));
+    RT_HIP(sync_all(r));
     prof_collect(r);
     return RT_OK;
 }
@@ -1129,14 +1202,14 @@ extern "C" int rt_renderer_sync(rt_renderer* r) {
 // kernel ids: 0 generate, 1 extend, 2 shade, 3 connect, 4 gather, 5 accumulate, 6 control
 extern "C" int rt_profile_enable(rt_renderer* r, int enable) {
     if (!r) { rt_set_error("rt_profile_enable: NULL"); return RT_ERR_INVALID; }
-    RT_HIP(hipStreamSynchronize(r->stream));
+    RT_HIP(sync_all(r));
     prof_collect(r);
     r->profile = enable != 0;
     return RT_OK;
 }
 extern "C" int rt_profile_read(rt_renderer* r, double* ms7, uint32_t* launches7, int reset) {
     if (!r || !ms7 || !launches7) { rt_set_error("rt_profile_read: NULL argument"); return RT_ERR_INVALID; }
-    RT_HIP(hipStreamSynchronize(r->stream));
+    RT_HIP(sync_all(r));
     prof_collect(r);
     for (int i = 0; i < RT_KID_COUNT; i++) { ms7[i] = r->prof_ms[i]; launches7[i] = r->prof_launches[i]; }
     if (reset) for (int i = 0; i < RT_KID_COUNT; i++) { r->prof_ms[i] = 0; r->prof_launches[i] = 0; }
@@ -1156,28 +1229,34 @@ extern "C" int rt_film_set_spp(rt_renderer* r, int spp) {
 }
 extern "C" int rt_film_read(rt_renderer* r, float* rgb, int* spp) {
     if (!r || !rgb) { rt_set_error("rt_film_read: NULL argument"); return RT_ERR_INVALID; }
-    RT_HIP(hipStreamSynchronize(r->stream));
+    RT_HIP(sync_all(r));
     RT_HIP(hipMemcpy(rgb, r->film, sizeof(float) * (size_t)r->W * r->H * 3, hipMemcpyDeviceToHost));
     if (spp) *spp = r->spp;
     return RT_OK;
 }
 extern "C" int rt_film_bind(rt_renderer* r, float* d_film) {
     if (!r) { rt_set_error("rt_film_bind: NULL"); return RT_ERR_INVALID; }
-    RT_HIP(hipStreamSynchronize(r->stream));
+    RT_HIP(sync_all(r));
     r->film = d_film ? d_film : r->film_own;
     return RT_OK;
 }
 extern "C" int rt_render_counters(rt_renderer* r, rt_counters* o, int reset) {
     if (!r || !o) { rt_set_error("rt_render_counters: NULL argument"); return RT_ERR_INVALID; }
-    RT_HIP(hipStreamSynchronize(r->stream));
+    RT_HIP(sync_all(r));
     Ctl c; DCounters d;
     RT_HIP(hipMemcpy(&c, r->ctl, sizeof(c), hipMemcpyDeviceToHost));
+    if (r->other_ready) {
+        Ctl c2;
+        RT_HIP(hipMemcpy(&c2, r->other.ctl, sizeof(c2), hipMemcpyDeviceToHost));
+        c.tot_closest += c2.tot_closest; c.tot_any += c2.tot_any;
+    }
     RT_HIP(hipMemcpy(&d, r->counters, sizeof(d), hipMemcpyDeviceToHost));
     o->closest_rays = c.tot_closest; o->any_rays = c.tot_any; o->nodes_visited = d.nodes; o->tris_tested = d.tris; o->exact_path_rays = d.exact;
     o->any_nodes_visited = d.any_nodes; o->any_tris_tested = d.any_tris;
-    o->lane_slots = d.slots; o->lane_busy = d.busy; o->any_lane_slots = d.any_slots; o->any_lane_busy = d.any_busy;
+    o->lane_slots = d.slots; o->lane_busy = d.busy; o->any_lane_slots = d.any_slots; o->any_lane_busy = d.any_busy; o->max_steps = d.max_steps; o->any_max_steps = d.any_max_steps;
     if (reset) {
         RT_HIP(hipMemset(r->ctl, 0, sizeof(Ctl)));
+        if (r->other_ready) RT_HIP(hipMemset(r->other.ctl, 0, sizeof(Ctl)));
         RT_HIP(hipMemset(r->counters, 0, sizeof(DCounters)));
     }
     return RT_OK;
@@ -1185,7 +1264,7 @@ extern "C" int rt_render_counters(rt_renderer* r, rt_counters* o, int reset) {
 extern "C" int rt_vpl_trace(rt_renderer* r, int n_vpls, uint64_t seed) {
     if (!r || n_vpls < 0) { rt_set_error("rt_vpl_trace: bad argument"); return RT_ERR_INVALID; }
     if (n_vpls > (1 << 20)) { rt_set_error("rt_vpl_trace: at most 2^20 light samples"); return RT_ERR_INVALID; }
-    RT_HIP(hipStreamSynchronize(r->stream));
+    RT_HIP(sync_all(r));
     r->n_vpl = 0; r->R.vpl_slots = 0;
     if (n_vpls == 0) return RT_OK;
     int rc;
@@ -1198,7 +1277,7 @@ extern "C" int rt_vpl_trace(rt_renderer* r, int n_vpls, uint64_t seed) {
     if ((rc = dev_alloc(r, &sp, (size_t)blocks * 64 * std::max<uint32_t>(r->scene->host.max_stack2, 2)))) return rc;
     LAUNCH(k_vpl_trace, blocks, 64, r->scene->d, r->R, n_vpls, seed, sp, r->ctl);
     RT_HIP(hipGetLastError());
-    RT_HIP(hipStreamSynchronize(r->stream));
+    RT_HIP(sync_all(r));
     r->n_vpl = n_vpls; r->R.vpl_slots = (uint32_t)n_vpls * 6;
     return RT_OK;
 }

@@ -94,4 +94,4 @@ struct DScene {
     int variant;              // experiment switch (RT_VARIANT env), 0 = default
 };
 
-struct DCounters { unsigned long long closest, any, nodes, tris, exact, any_nodes, any_tris, slots, busy, any_slots, any_busy; };
+struct DCounters { unsigned long long closest, any, nodes, tris, exact, any_nodes, any_tris, slots, busy, any_slots, any_busy, max_steps, any_max_steps; };

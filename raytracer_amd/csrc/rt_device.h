@@ -207,6 +207,75 @@ __device__ bool rt_walk_reference(const DScene& S, f3 o, f3 dir, float maxT, Hit
     return true;
 }
 
+// ---- the walk of mode-0 rays that may not take the 4-wide tree (a zero / denormal direction component: 1/dir is
+// infinite or huge, slab products can be NaN and box containment no longer implies test monotonicity).  Every node of
+// the reference tree on the way down is tested with the reference's own expression (rt_box_exact), so the candidate
+// set is the reference's by construction; what this walk adds over rt_walk_reference is near-first order and a
+// conservative cull that only looks at the axes where 1/dir is tame (a box is skipped when, grown by the same slack
+// as in the wide walk, it lies entirely behind the origin or entirely beyond the best hit on those axes).  Without
+// it one such ray pierces thousands of boxes of a 1 M-triangle scene unculled and, alone in its wave, sets the
+// duration of the whole launch: 0.6-2 ms per k_extend launch before, measured.
+template <bool ANY, bool COUNT>
+__device__ bool rt_walk_exact(const DScene& S, f3 o, f3 dir, float maxT, HitRec& best, uint32_t* spill, uint32_t gstride,
+                              uint32_t& c_nodes, uint32_t& c_tris) {
+    const f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);  // Ray::init (Geometry.h:23)
+    const bool tx = fabsf(inv.x) < 1e18f, ty = fabsf(inv.y) < 1e18f, tz = fabsf(inv.z) < 1e18f;
+    const float scale = fmaxf(S.abs_max, fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))));
+    const float delta = scale * 6.103515625e-05f;
+    const f3 pad = mk3(delta * fabsf(inv.x), delta * fabsf(inv.y), delta * fabsf(inv.z));
+    auto test = [&](uint32_t ni, float& key) -> bool {
+        const float4* q = reinterpret_cast<const float4*>(S.nodes2 + ni);
+        float4 a = q[0], b = q[1];
+        f3 lo = mk3(a.x, a.y, a.z), hi = mk3(b.x, b.y, b.z);
+        if (COUNT) c_nodes++;
+        float tb;
+        bool pass = rt_box_exact(lo, hi, o, inv, tb);
+        if (ANY) pass = pass && !(tb > maxT);
+        if (!pass) return false;
+        float lo_ = -RT_INF, hi_ = RT_INF;
+        if (tx) { float t0 = (lo.x - o.x) * inv.x, t1 = (hi.x - o.x) * inv.x; lo_ = fmaxf(lo_, fminf(t0, t1) - pad.x); hi_ = fminf(hi_, fmaxf(t0, t1) + pad.x); }
+        if (ty) { float t0 = (lo.y - o.y) * inv.y, t1 = (hi.y - o.y) * inv.y; lo_ = fmaxf(lo_, fminf(t0, t1) - pad.y); hi_ = fminf(hi_, fmaxf(t0, t1) + pad.y); }
+        if (tz) { float t0 = (lo.z - o.z) * inv.z, t1 = (hi.z - o.z) * inv.z; lo_ = fmaxf(lo_, fminf(t0, t1) - pad.z); hi_ = fminf(hi_, fmaxf(t0, t1) + pad.z); }
+        if (hi_ < 0.0f) return false;
+        if (!ANY && lo_ > best.t) return false;
+        key = lo_;
+        return true;
+    };
+    float key;
+    if (!test(0u, key)) return true;
+    uint32_t sp = 0, cur = 0;
+    for (;;) {
+        const float4* q = reinterpret_cast<const float4*>(S.nodes2 + cur);
+        const int left = __float_as_int(q[0].w), right = __float_as_int(q[1].w);
+        if (left < 0 && right < 0) {
+            const float4 c = q[2];
+            const int first = __float_as_int(c.x), count = __float_as_int(c.y);
+            for (int k = 0; k < count; k++) {
+                float t, u, v;
+                if (COUNT) c_tris++;
+                if (rt_tri_test(S.tris + first + k, o, dir, t, u, v)) {
+                    if (ANY) { if (t < maxT) return false; }
+                    else if (t < best.t || (t == best.t && (uint32_t)(first + k) < best.rank)) { best.t = t; best.u = u; best.v = v; best.rank = (uint32_t)(first + k); }
+                }
+            }
+        } else {
+            float kl = 0, kr = 0;
+            const bool pl = left >= 0 && test((uint32_t)left, kl), pr = right >= 0 && test((uint32_t)right, kr);
+            if (pl && pr) {
+                const bool swap = kr < kl;
+                spill[(size_t)(sp++) * gstride] = (uint32_t)(swap ? left : right);
+                cur = (uint32_t)(swap ? right : left);
+                continue;
+            }
+            if (pl) { cur = (uint32_t)left; continue; }
+            if (pr) { cur = (uint32_t)right; continue; }
+        }
+        if (!sp) break;
+        cur = spill[(size_t)(--sp) * gstride];
+    }
+    return true;
+}
+
 #define RT_CSWAP(ka, ra, kb, rb)                                  \
     {                                                             \
         bool s_ = kb < ka;                                        \
@@ -290,7 +359,12 @@ __device__ __forceinline__ bool rt_node_eval(const DScene& S, Walk& w, TravStack
 #undef RT_SLOT
     uint32_t r0 = ch.x, r1 = ch.y, r2 = ch.z, r3 = ch.w;
     if (!ANY) {
-        RT_CSWAP(k0, r0, k1, r1) RT_CSWAP(k2, r2, k3, r3) RT_CSWAP(k0, r0, k2, r2) RT_CSWAP(k1, r1, k3, r3) RT_CSWAP(k1, r1, k2, r2)
+#ifndef RT_SORT_SWAPS
+#define RT_SORT_SWAPS 5
+#endif
+        RT_CSWAP(k0, r0, k1, r1) RT_CSWAP(k2, r2, k3, r3) RT_CSWAP(k0, r0, k2, r2)   // the nearest child is in slot 0 now
+        if (RT_SORT_SWAPS >= 4) RT_CSWAP(k1, r1, k3, r3)
+        if (RT_SORT_SWAPS >= 5) RT_CSWAP(k1, r1, k2, r2)
     } else {  // no order needed: compact the passing children to the front
         if (!(k2 < RT_INF)) { k2 = k3; r2 = r3; k3 = RT_INF; }
         if (!(k1 < RT_INF)) { k1 = k2; r1 = r2; k2 = k3; r2 = r3; k3 = RT_INF; }
@@ -398,7 +472,8 @@ __device__ __forceinline__ bool rt_closest_begin(const DScene& S, f3 o, f3 dir, 
     f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
     if (mode == 0 && rt_ray_is_tame(inv)) { rt_walk_init(S, w, o, dir, inv, 0.0f); return false; }
     if (COUNT) cexact++;
-    rt_walk_reference<false, COUNT>(S, o, dir, 0.0f, w.best, spill2, gstride, cn, ct);
+    if (mode == 0) rt_walk_exact<false, COUNT>(S, o, dir, 0.0f, w.best, spill2, gstride, cn, ct);
+    else rt_walk_reference<false, COUNT>(S, o, dir, 0.0f, w.best, spill2, gstride, cn, ct);
     return true;
 }
 // Scene::visible (Scene.h:169-178), set-up half: true when `visible` is already known.
@@ -415,7 +490,8 @@ __device__ __forceinline__ bool rt_visible_begin(const DScene& S, f3 p1, f3 p2, 
     if (mode == 0 && rt_ray_is_tame(inv)) { rt_walk_init(S, w, o, dir, inv, maxT); return false; }
     if (COUNT) cexact++;
     HitRec dummy;
-    visible = rt_walk_reference<true, COUNT>(S, o, dir, maxT, dummy, spill2, gstride, cn, ct);
+    visible = mode == 0 ? rt_walk_exact<true, COUNT>(S, o, dir, maxT, dummy, spill2, gstride, cn, ct)
+                        : rt_walk_reference<true, COUNT>(S, o, dir, maxT, dummy, spill2, gstride, cn, ct);
     return true;
 }
 
@@ -436,7 +512,7 @@ template <bool ANY, bool COUNT, class Job, class Source>
 __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, Source& src, int mode, TravStack& st, uint32_t* spill2,
                                                    uint32_t gstride, uint32_t& cn, uint32_t& ct, uint32_t& cx, DCounters* counters) {
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t c_slots = 0, c_busy = 0;
+    uint32_t c_slots = 0, c_busy = 0, c_mine = 0, c_max = 0;
     Walk w;
     uint32_t item = 0;
     bool busy = false, done = false, visible = true;
@@ -461,12 +537,13 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
                     bool fin = ANY ? rt_visible_begin<COUNT>(S, a, b, mode, w, visible, spill2, gstride, cn, ct, cx)
                                    : rt_closest_begin<COUNT>(S, a, b, mode, w, spill2, gstride, cn, ct, cx);
                     busy = !fin; done = fin;
+                    if (COUNT) c_mine = 0;
                 }
             }
             pb += take;
             continue;  // re-count: short grants and dead items leave lanes idle
         }
-        if (COUNT) { c_slots++; c_busy += busy ? 1u : 0u; }
+        if (COUNT) { c_slots++; c_busy += busy ? 1u : 0u; c_mine += busy ? 1u : 0u; c_max = c_mine > c_max ? c_mine : c_max; }
         if (rt_vote_step<ANY, COUNT>(S, w, busy, st, cn, ct)) {
             busy = false; done = true;
             if (ANY) visible = !w.occluded;
@@ -475,6 +552,7 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
     if (COUNT) {
         atomicAdd(ANY ? &counters->any_slots : &counters->slots, (unsigned long long)c_slots);
         atomicAdd(ANY ? &counters->any_busy : &counters->busy, (unsigned long long)c_busy);
+        atomicMax(ANY ? &counters->any_max_steps : &counters->max_steps, (unsigned long long)c_max);
     }
 }
 

@@ -43,7 +43,7 @@ for name, rays in sets.items():
         nodes, tris = c["nodes_visited"] / len(rays), c["tris_tested"] / len(rays)
         bpr = 24 + 20 + nodes * 128 + tris * 64
         print(f"{name:18s} closest mode{mode}: {len(rays)/best/1e6:9.1f} Mrays/s  nodes/ray {nodes:.1f} tris/ray {tris:.1f} "
-              f"alg bytes/ray {bpr:.0f} -> {len(rays)*bpr/best/1e9:.0f} GB/s  exact-path rays {c['exact_path_rays']} lane occ {c['lane_busy']/max(c['lane_slots'],1):.3f}", flush=True)
+              f"alg bytes/ray {bpr:.0f} -> {len(rays)*bpr/best/1e9:.0f} GB/s  exact-path rays {c['exact_path_rays']} lane occ {c['lane_busy']/max(c['lane_slots'],1):.3f} max steps/ray {c['max_steps']} (mean {(c['nodes_visited']+c['tris_tested'])/len(rays):.0f})", flush=True)
 segs = scenes.shadow_segments(s, a.n, 3)
 d_s = torch.from_numpy(segs).to(dev)
 d_v = torch.empty(len(segs), dtype=torch.uint8, device=dev)
@@ -53,4 +53,4 @@ for _ in range(a.reps):
     torch.cuda.synchronize(); t = time.perf_counter()
     sc.visible_dev(d_s.data_ptr(), len(segs), d_v.data_ptr(), 0)
     torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
-print(f"shadow any-hit: {len(segs)/min(ts)/1e6:9.1f} Mrays/s nodes/ray {c['any_nodes_visited']/len(segs):.1f} tris/ray {c['any_tris_tested']/len(segs):.1f} lane occ {c['any_lane_busy']/max(c['any_lane_slots'],1):.3f}", flush=True)
+print(f"shadow any-hit: {len(segs)/min(ts)/1e6:9.1f} Mrays/s nodes/ray {c['any_nodes_visited']/len(segs):.1f} tris/ray {c['any_tris_tested']/len(segs):.1f} lane occ {c['any_lane_busy']/max(c['any_lane_slots'],1):.3f} max steps/ray {c['any_max_steps']}", flush=True)
