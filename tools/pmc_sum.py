@@ -14,7 +14,7 @@ for d in sys.argv[1:]:
             o = out.setdefault(k, {}).setdefault(row["Counter_Name"], {"sum": 0.0, "ids": set()})
             o["sum"] += float(row["Counter_Value"])
             o["ids"].add(row["Dispatch_Id"])
-res = {"command": "rocprofv3 --pmc <group> -- python3 bench.py --no-cpu-baseline --steps 8 --warmup 0 (one run per counter group, tools/pmc.sh)",
+res = {"command": "rocprofv3 --pmc <group> -- python3 bench.py --no-cpu-baseline --warmup 0 (one run per counter group, tools/pmc.sh)",
        "counters": {k: {c: {"sum": v["sum"], "dispatches": len(v["ids"])} for c, v in sorted(cs.items())} for k, cs in sorted(out.items())}}
 
 
