@@ -184,7 +184,6 @@ extern "C" int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_
     d.root_ref = d.n_tris ? 0u : RT_REF_EMPTY;
     d.max_stack4 = h.max_stack4; d.max_stack2 = h.max_stack2;
     d.abs_max = h.abs_max;
-    d.variant = getenv("RT_VARIANT") ? atoi(getenv("RT_VARIANT")) : 0;
     memcpy(d.bg_colour, h.bg_colour, 12); d.bg_kind = h.bg_kind; d.bg_tex = h.bg_tex;
     memcpy(d.scene_centre, h.centre, 12); d.scene_radius = h.radius;
 

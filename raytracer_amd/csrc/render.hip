@@ -53,13 +53,6 @@ __device__ __forceinline__ unsigned long long fetch_chunk(unsigned long long* wo
 // A wave takes RT_FETCH_CHUNKS x 64 consecutive items per atomic: one contended device-scope atomic costs ~11 ns
 // (MI355X_MICROARCH.md "fanin"/"dequeue"), so per-64-item fetches alone would cap a kernel at ~5.8 G items/s.
 #define RT_FETCH_CHUNKS 4
-__device__ __forceinline__ unsigned long long fetch_chunks(unsigned long long* work, unsigned chunks) {
-    unsigned long long base = 0;
-    if ((threadIdx.x & 63) == 0) base = atomicAdd(work, 64ULL * chunks);
-    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
-    unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
 #ifndef RT_XCD_SHARD
 #define RT_XCD_SHARD 1
 #endif

@@ -91,7 +91,6 @@ struct DScene {
     uint32_t bg_kind; int32_t bg_tex;
     float scene_centre[3], scene_radius;   // SceneBounds (Lights.h:12, SceneLoader.h:286-287)
     DCamera cam;
-    int variant;              // experiment switch (RT_VARIANT env), 0 = default
 };
 
 struct DCounters { unsigned long long closest, any, nodes, tris, exact, any_nodes, any_tris, slots, busy, any_slots, any_busy, max_steps, any_max_steps; };
