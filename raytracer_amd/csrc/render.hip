@@ -28,7 +28,7 @@ struct Ctl {
     uint32_t n_gather;
     unsigned long long work[4];  // extend, shade, connect, gather
     unsigned long long tot_closest, tot_any;
-    unsigned long long work_x[2][8][16];  // [extend|connect][XCD shard], one 128-B line each
+    unsigned long long work_x[3][8][16];  // [extend|connect|gather][XCD shard], one 128-B line each
 };
 
 struct RBuf {  // device buffers of one renderer
@@ -176,7 +176,7 @@ __global__ void k_ctl_reset(Ctl* ctl, int cur, int first, uint32_t first_count, 
     ctl->n_shadow = 0;
     ctl->n_gather = 0;
     for (int i = 0; i < 4; i++) ctl->work[i] = 0;
-    for (int k = 0; k < 2; k++) for (int i = 0; i < 8; i++) ctl->work_x[k][i][0] = 0;
+    for (int k = 0; k < 3; k++) for (int i = 0; i < 8; i++) ctl->work_x[k][i][0] = 0;
 }
 __global__ void k_ctl_final(Ctl* ctl) {
     ctl->tot_any += ctl->n_shadow;
@@ -815,60 +815,85 @@ __global__ __launch_bounds__(64) void k_vpl_trace(DScene S, RBuf R, int n_vpl, u
 
 // computeVPLContribution (Renderer.h:870-907): one lane per shading point, VPLs in slot order; cosine tests run
 // before the shadow ray (same sum, fewer rays than upstream which traces first).
-__global__ __launch_bounds__(RT_BLOCK) void k_gather(DScene S, RBuf R, Ctl* ctl, uint32_t* spill4, uint32_t* spill2) {
+// One item = one (shading point, VPL) pair, VPL-major so that the lanes of a wave read consecutive requests and add to
+// different paths.  The pairs go through the same persistent any-hit driver as the NEE shadow rays (lane refill, voted
+// steps); a visible pair adds its term to the path's radiance with float atomics, so the order of the sum over VPLs is
+// not fixed (upstream sums in VPL order, Renderer.h:870-907; the terms are the same).
+struct GatherJob {
+    const DScene& S;
+    const RBuf& R;
+    uint32_t n, v0;
+    unsigned long long nrays;
+    __device__ __forceinline__ bool terms(uint32_t k, Shading& sd, f3& vx, f3& vn, f3& wi, float& G, float4& r0, float4& r3, col3& T, uint32_t& path, uint32_t& v) const {
+        v = v0 + k / n;
+        const uint32_t i = k - (k / n) * n;
+        const float4* r = R.vpl + (size_t)v * 4;
+        r3 = r[3];
+        if (r3.w == 0.0f) return false;
+        r0 = r[0];
+        const float4 r1 = r[1];
+        const float4* e = R.gather + (size_t)i * 4;
+        const float4 a = e[0], b = e[1];
+        sd.x = mk3(a.x, a.y, a.z); sd.sN = mk3(b.x, b.y, b.z);
+        vx = mk3(r0.x, r0.y, r0.z); vn = mk3(r1.x, r1.y, r1.z);
+        wi = vx - sd.x;
+        float dist = len3(wi);
+        wi = norm3(wi);
+        float cx_ = dot3(sd.sN, wi), cxi = dot3(vn, -wi);
+        if (cx_ <= 0.0f || cxi <= 0.0f) return false;
+        G = cx_ * cxi / (dist * dist);
+        if (G <= 0.0f) return false;
+        const float4 c = e[2], dd = e[3];
+        sd.gN = sd.sN; sd.wo = mk3(c.x, c.y, c.z); sd.tu = b.w; sd.tv = c.w; sd.mat = __float_as_uint(dd.w);
+        T = mkc(dd.x, dd.y, dd.z);
+        path = __float_as_uint(a.w);
+        return true;
+    }
+    __device__ __forceinline__ bool load(uint32_t k, f3& p1, f3& p2) {
+        Shading sd; f3 vx, vn, wi; float G; float4 r0, r3; col3 T; uint32_t path, v;
+        if (!terms(k, sd, vx, vn, wi, G, r0, r3, T, path, v)) return false;
+        p1 = sd.x; p2 = vx;
+        nrays++;
+        return true;
+    }
+    __device__ __forceinline__ void retire(uint32_t k, const Walk&, bool visible) {
+        if (!visible) return;
+        Shading sd; f3 vx, vn, wi; float G; float4 r0, r3; col3 T; uint32_t path, v;
+        if (!terms(k, sd, vx, vn, wi, G, r0, r3, T, path, v)) return;
+        sd.frame = frame_from(sd.sN);
+        col3 fx = bsdf_eval(S, sd, wi);
+        col3 Le = mkc(r3.x, r3.y, r3.z), term;
+        int vmat = __float_as_int(r0.w);
+        if (vmat < 0 || (S.mats[vmat].flags & RT_MF_LIGHT)) term = (fx * G) * Le;
+        else {
+            const float4* r = R.vpl + (size_t)v * 4;
+            const float4 r1 = r[1], r2 = r[2];
+            Shading vs;
+            vs.x = vx; vs.sN = vn; vs.gN = vn; vs.wo = mk3(r2.x, r2.y, r2.z); vs.tu = r1.w; vs.tv = r2.w; vs.mat = (uint32_t)vmat;
+            vs.frame = frame_from(vn);
+            col3 fxi = bsdf_eval(S, vs, -wi);
+            term = ((fx * G) * fxi) * Le;
+        }
+        col3 add = T * term;
+        float* L = reinterpret_cast<float*>(R.rad + path);
+        atomicAdd(L + 0, add.r); atomicAdd(L + 1, add.g); atomicAdd(L + 2, add.b);
+    }
+};
+// VPL slots [v0, v0 + nv) against every gather request of the bounce
+__global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_gather(DScene S, RBuf R, Ctl* ctl, uint32_t v0, uint32_t nv, uint32_t* spill4, uint32_t* spill2, DCounters* counters) {
     __shared__ uint32_t lds_stack[RT_STACK_WORDS];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
     RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
     const uint32_t n = ctl->n_gather;
+    if (n == 0) return;
+    const uint32_t items = n * nv;   // the host keeps cap * nv below 2^31
     uint32_t cn = 0, ct = 0, cx = 0;
-    unsigned long long nrays = 0;
-    for (;;) {
-        unsigned long long base = fetch_chunk(&ctl->work[3]);
-        if (base >= n) break;
-        uint32_t i = (uint32_t)base + (threadIdx.x & 63);
-        if (i < n) {
-            const float4* e = R.gather + (size_t)i * 4;
-            float4 a = e[0], b = e[1], c = e[2], dd = e[3];
-            Shading sd;
-            sd.x = mk3(a.x, a.y, a.z); sd.sN = mk3(b.x, b.y, b.z); sd.gN = sd.sN; sd.wo = mk3(c.x, c.y, c.z);
-            sd.tu = b.w; sd.tv = c.w; sd.mat = __float_as_uint(dd.w);
-            sd.frame = frame_from(sd.sN);
-            col3 sum = mkc(0, 0, 0);
-            for (uint32_t v = 0; v < R.vpl_slots; v++) {
-                const float4* r = R.vpl + (size_t)v * 4;
-                float4 r3 = r[3];
-                if (r3.w == 0.0f) continue;
-                float4 r0 = r[0], r1 = r[1];
-                f3 vx = mk3(r0.x, r0.y, r0.z), vn = mk3(r1.x, r1.y, r1.z);
-                f3 wi = vx - sd.x;
-                float dist = len3(wi);
-                wi = norm3(wi);
-                float cx_ = dot3(sd.sN, wi), cxi = dot3(vn, -wi);
-                if (cx_ <= 0.0f || cxi <= 0.0f) continue;
-                float G = cx_ * cxi / (dist * dist);
-                if (G <= 0.0f) continue;
-                nrays++;
-                if (!rt_visible<false>(S, sd.x, vx, 0, st, spill2 + gtid, gstride, cn, ct, cx)) continue;
-                col3 fx = bsdf_eval(S, sd, wi);
-                col3 Le = mkc(r3.x, r3.y, r3.z);
-                int vmat = __float_as_int(r0.w);
-                if (vmat < 0 || (S.mats[vmat].flags & RT_MF_LIGHT)) sum = sum + ((fx * G) * Le);
-                else {
-                    float4 r2 = r[2];
-                    Shading vs;
-                    vs.x = vx; vs.sN = vn; vs.gN = vn; vs.wo = mk3(r2.x, r2.y, r2.z); vs.tu = r1.w; vs.tv = r2.w; vs.mat = (uint32_t)vmat;
-                    vs.frame = frame_from(vn);
-                    col3 fxi = bsdf_eval(S, vs, -wi);
-                    sum = sum + (((fx * G) * fxi) * Le);
-                }
-            }
-            uint32_t path = __float_as_uint(a.w);
-            col3 add = mkc(dd.x, dd.y, dd.z) * sum;
-            float4 L = R.rad[path];
-            R.rad[path] = make_float4(L.x + add.r, L.y + add.g, L.z + add.b, L.w);
-        }
-    }
-    if (nrays) atomicAdd(&ctl->tot_any, nrays);
+    GatherJob job{S, R, n, v0, 0ULL};
+    XcdSource src; src.xf.init(items); src.w = ctl->work_x[2]; src.n = items;
+    rt_persistent_walk<true, false>(S, job, src, 0, st, spill2 + gtid, gstride, cn, ct, cx, counters);
+    unsigned long long total = job.nrays;
+    for (int o = 32; o; o >>= 1) total += __shfl_xor(total, o);
+    if ((threadIdx.x & 63) == 0 && total) atomicAdd(&ctl->tot_any, total);
 }
 
 // ------------------------------------------------------------------------------------------------ debug probes
@@ -1081,7 +1106,13 @@ static int render_path_like(rt_renderer* r, int mode, uint32_t batch, uint64_t s
         else LAUNCHK(RT_KID_SHADE, k_shade<false>, r->flat_blocks / 2, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
         if (r->count_enabled) LAUNCHK(RT_KID_CONNECT, k_connect<true>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
         else LAUNCHK(RT_KID_CONNECT, k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
-        if (radiosity) LAUNCHK(RT_KID_GATHER, k_gather, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2);
+        if (radiosity) {
+            const uint32_t per = std::max<uint32_t>(1u, (1u << 31) / R.cap);   // item indices are 32-bit: requests x VPLs per launch < 2^31
+            for (uint32_t v0 = 0; v0 < R.vpl_slots; v0 += per) {
+                if (v0) RT_HIP(hipMemsetAsync(&r->ctl->work_x[2], 0, sizeof(r->ctl->work_x[2]), r->stream));
+                LAUNCHK(RT_KID_GATHER, k_gather, r->trav_blocks, RT_BLOCK, S, R, r->ctl, v0, std::min<uint32_t>(per, R.vpl_slots - v0), r->spill4, r->spill2, r->counters);
+            }
+        }
     }
     LAUNCH(k_ctl_final, 1, 1, r->ctl);
     if (r->acc_pending) RT_HIP(hipStreamWaitEvent(r->stream, r->acc_event, 0));   // film += in batch order, whichever lane ran the batch
