@@ -446,37 +446,47 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_connect(DScene S, R
 }
 
 // connectToCamera (Renderer.h:669-692): projection, visibility to the lens, We = 1/(Afilm cos^4), atomic splat
-__global__ __launch_bounds__(RT_BLOCK) void k_connect_camera(DScene S, RBuf R, Ctl* ctl, float* film, uint32_t* spill4, uint32_t* spill2) {
+struct CameraJob {
+    const DScene& S;
+    const RBuf& R;
+    float* film;
+    __device__ __forceinline__ bool load(uint32_t i, f3& p1, f3& p2) {
+        float4 a = R.shadow[(size_t)i * 3];
+        float x, y;
+        p1 = mk3(a.x, a.y, a.z);
+        if (!camera_project(S.cam, p1, x, y)) return false;
+        p2 = ld3(S.cam.origin);
+        return true;
+    }
+    __device__ __forceinline__ void retire(uint32_t i, const Walk&, bool visible) {
+        if (!visible) return;
+        const DCamera& cam = S.cam;
+        const float4* e = R.shadow + (size_t)i * 3;
+        float4 a = e[0];
+        f3 p = mk3(a.x, a.y, a.z), org = ld3(cam.origin);
+        float x, y;
+        if (!camera_project(cam, p, x, y)) return;
+        f3 cd = norm3(p - org);
+        float costheta = dot3(ld3(cam.view_dir), cd);
+        if (costheta <= 0) return;
+        float we = (float)(1.f / (cam.Afilm * pow((double)costheta, 4.0)));
+        float4 c = e[2];
+        int px = (int)x, py = (int)y;  // Film::splat with BoxFilter (Imaging.h:224)
+        if (px >= 0 && px < cam.iw && py >= 0 && py < cam.ih) {
+            float* f = film + ((size_t)py * cam.iw + px) * 3;
+            atomicAdd(f + 0, c.x * we); atomicAdd(f + 1, c.y * we); atomicAdd(f + 2, c.z * we);
+        }
+    }
+};
+__global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_connect_camera(DScene S, RBuf R, Ctl* ctl, float* film, uint32_t* spill4, uint32_t* spill2, DCounters* counters) {
     __shared__ uint32_t lds_stack[RT_STACK_WORDS];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
     RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
     const uint32_t n = ctl->n_shadow;
     uint32_t cn = 0, ct = 0, cx = 0;
-    const DCamera& cam = S.cam;
-    for (;;) {
-        unsigned long long base = fetch_chunk(&ctl->work[2]);
-        if (base >= n) break;
-        uint32_t i = (uint32_t)base + (threadIdx.x & 63);
-        if (i < n) {
-            const float4* e = R.shadow + (size_t)i * 3;
-            float4 a = e[0];
-            f3 p = mk3(a.x, a.y, a.z);
-            float x, y;
-            if (!camera_project(cam, p, x, y)) continue;
-            f3 org = ld3(cam.origin);
-            if (!rt_visible<false>(S, p, org, 0, st, spill2 + gtid, gstride, cn, ct, cx)) continue;
-            f3 cd = norm3(p - org);
-            float costheta = dot3(ld3(cam.view_dir), cd);
-            if (costheta <= 0) continue;
-            float we = (float)(1.f / (cam.Afilm * pow((double)costheta, 4.0)));
-            float4 c = e[2];
-            int px = (int)x, py = (int)y;  // Film::splat with BoxFilter (Imaging.h:224)
-            if (px >= 0 && px < cam.iw && py >= 0 && py < cam.ih) {
-                float* f = film + ((size_t)py * cam.iw + px) * 3;
-                atomicAdd(f + 0, c.x * we); atomicAdd(f + 1, c.y * we); atomicAdd(f + 2, c.z * we);
-            }
-        }
-    }
+    CameraJob job{S, R, film};
+    XcdSource src; src.xf.init(n); src.w = ctl->work_x[1]; src.n = n;
+    rt_persistent_walk<true, false>(S, job, src, 0, st, spill2 + gtid, gstride, cn, ct, cx, counters);
 }
 
 // ------------------------------------------------------------------------------------------------ accumulate
@@ -1143,14 +1153,14 @@ static int render_light(rt_renderer* r, uint32_t batch, uint64_t seed, uint64_t 
     const uint32_t n = npix * batch;  // W*H light paths per spp (Renderer.h:331-337)
     LAUNCH(k_ctl_reset, 1, 1, r->ctl, 0, 1, 0u, 0u);
     LAUNCHK(RT_KID_GENERATE, k_lt_generate, r->flat_blocks, 256, S, R, r->ctl, n, npix, seed, first_sample);
-    LAUNCHK(RT_KID_CONNECT, k_connect_camera, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->spill4, r->spill2);
+    LAUNCHK(RT_KID_CONNECT, k_connect_camera, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->spill4, r->spill2, r->counters);
     for (int b = 0; b < RT_MAX_DEPTH + 2; b++) {
         int cur = b & 1;
         LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n, n);
         LAUNCHK(RT_KID_EXTEND, (k_extend<true, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
         LAUNCH(k_bin, r->flat_blocks / 2, RT_BIN_BLOCK, R, r->ctl, cur, b == 0 ? 1 : 0);
         LAUNCHK(RT_KID_SHADE, k_lt_shade, r->flat_blocks, 256, S, R, r->ctl, cur);
-        LAUNCHK(RT_KID_CONNECT, k_connect_camera, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->spill4, r->spill2);
+        LAUNCHK(RT_KID_CONNECT, k_connect_camera, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->spill4, r->spill2, r->counters);
     }
     LAUNCH(k_ctl_final, 1, 1, r->ctl);
     RT_HIP(hipGetLastError());
