@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--detail", type=float, default=1.0, help="scene tessellation (1.0 = ~1.1 M triangles)")
     ap.add_argument("--scene", default="bathroom")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=1)
+    ap.add_argument("--cpu-spp", type=int, default=8)
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

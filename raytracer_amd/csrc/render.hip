@@ -304,7 +304,10 @@ __global__ __launch_bounds__(RT_BIN_BLOCK) void k_bin(RBuf R, Ctl* ctl, int cur,
 // pathTraceRadiosity (Renderer.h:931).
 #define RT_SHADE_BLOCK 512
 template <bool RADIOSITY>
-__global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene S, RBuf R, Ctl* ctl, int cur, int direct_only) {
+#ifndef RT_SHADE_OCC
+#define RT_SHADE_OCC 2   // blocks of 512 per CU the register budget is set for
+#endif
+__global__ __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_OCC) void k_shade(DScene S, RBuf R, Ctl* ctl, int cur, int direct_only) {
     __shared__ unsigned long long s_base;
     __shared__ uint32_t s_app[3 * (RT_SHADE_BLOCK / 64 + 1)];
     uint32_t cnt[RT_NCLASS], total = 0;
@@ -1197,20 +1200,25 @@ extern "C" int rt_render(rt_renderer* r, int mode, int spp, uint64_t seed, uint6
     if (mode == RT_MODE_LIGHT) bmax = std::max<uint32_t>(1, r->R.cap / ((uint32_t)r->W * r->H));
     if (mode == RT_MODE_MLT) bmax = std::max<uint32_t>(1, r->R.cap / RT_MLT_PATHS);  // one chain per spp, all chains of a batch side by side
     int done = 0;
-    if (mode == RT_MODE_PATH && spp >= 2 && RT_LANES > 1) {
-        // at least two batches, alternating between the two lanes (streams)
+    if ((mode == RT_MODE_PATH || mode == RT_MODE_LIGHT) && spp >= 2 && RT_LANES > 1) {
+        // at least two batches, alternating between the two lanes (streams).  Path tracing chains its film accumulation by
+        // an event (fixed fp32 sum order); the light tracer's splats are atomics and need no order.
         int rc = ensure_other_lane(r);
         if (rc) return rc;
         uint32_t nb = std::max<uint32_t>(2u, ((uint32_t)spp + bmax - 1) / bmax);
         for (uint32_t i = 0; i < nb; i++) {
             uint32_t b = (uint32_t)spp / nb + (i < (uint32_t)spp % nb ? 1u : 0u);
             use_lane(r, (int)(i & 1u));
-            rc = render_path_like(r, mode, b, seed, first_sample + done);
+            rc = mode == RT_MODE_LIGHT ? render_light(r, b, seed, first_sample + done) : render_path_like(r, mode, b, seed, first_sample + done);
             if (rc) { use_lane(r, 0); return rc; }
             done += (int)b;
         }
+        use_lane(r, 1);
+        hipError_t e1 = hipEventRecord(r->acc_event, r->stream);
         use_lane(r, 0);
+        RT_HIP(e1);
         RT_HIP(hipStreamWaitEvent(r->stream, r->acc_event, 0));   // whatever is queued on lane 0 next sees the complete film
+        r->acc_pending = true;
     }
     while (done < spp) {
         uint32_t b = std::min<uint32_t>(bmax, (uint32_t)(spp - done));
