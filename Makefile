@@ -10,7 +10,7 @@ HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-slp-vect
 
 all: product oracle host
 # C++ host mirror + headless driver (links the C ABI only; no HIP code on this side)
-host: raytracer_amd/host/rtamd_cli
+host: raytracer_amd/host/rtamd_cli tests/host/rttest
 raytracer_amd/host/rtamd_cli: raytracer_amd/host/main.cpp raytracer_amd/host/rtamd.hpp raytracer_amd/host/gem.hpp include/rtamd.h raytracer_amd/librtamd.so
 	g++ -std=c++17 -O2 -ffp-contract=off -Wall -Wextra raytracer_amd/host/main.cpp -o $@ -Lraytracer_amd -lrtamd -Wl,-rpath,'$$ORIGIN/..'
 product: raytracer_amd/librtamd.so
@@ -21,3 +21,6 @@ oracle:
 clean:
 	rm -f raytracer_amd/librtamd.so oracle/liboracle.so raytracer_amd/host/rtamd_cli
 .PHONY: all product oracle host clean
+# the reference's RTTest known-answer case through the C++ host mirror (run by tests/test_host_cpp.py on a GPU)
+tests/host/rttest: tests/host/rttest.cpp raytracer_amd/host/rtamd.hpp include/rtamd.h raytracer_amd/librtamd.so
+	g++ -std=c++17 -O2 -ffp-contract=off -Wall -Wextra tests/host/rttest.cpp -o $@ -Lraytracer_amd -lrtamd -Wl,-rpath,'$$ORIGIN/../../raytracer_amd'

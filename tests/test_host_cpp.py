@@ -94,3 +94,13 @@ def test_cli_builtin_cornell_and_modes(tmp_path):
         assert r.returncode == 0, r.stderr
         img = read_hdr(str(out))
         assert img.shape == (48, 48, 3) and np.isfinite(img).all() and img.mean() > 0
+
+
+@pytest.mark.gpu
+def test_reference_unit_test_through_cpp_host():
+    """RTTest.cpp's triangle case via rtamd::Scene::traverse / visible (tests/host/rttest.cpp)."""
+    exe = os.path.join(ROOT, "tests", "host", "rttest")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", ROOT, "host"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
