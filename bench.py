@@ -110,7 +110,8 @@ def main():
         dt_max, rays_all = dt, float(rays)
     spp_total = K * world
     finite = torch.isfinite(film)
-    film_mean = float(film[finite].mean()) / max(spp_total if world > 1 else K, 1)
+    film_mean = float(film[finite].double().mean()) / max(spp_total if world > 1 else K, 1)  # fireflies reach 1e36: sum in f64
+    film_median = float(film[finite].median()) / max(spp_total if world > 1 else K, 1)
     film_nan = int((~finite).sum())  # upstream's estimators can return inf/NaN (e.g. MirrorBSDF divides by wi.z, Materials.h:264)
 
     out = None
@@ -158,7 +159,7 @@ def main():
                 "triangles": info["n_tris"], "width": W, "height": H, "spp_per_rank": K,
                 "parallelism": f"sample-partition x{world}" + (", RCCL film all-reduce" if world > 1 else "") + ", 2 streams per GPU",
                 "rays_per_pixel_sample": rays / (W * H * K),
-                "film_mean": film_mean, "film_nonfinite_values": film_nan,
+                "film_mean": film_mean, "film_median": film_median, "film_nonfinite_values": film_nan,
             },
             "roofline": {
                 "bound": "hbm",

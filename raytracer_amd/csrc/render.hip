@@ -26,6 +26,8 @@ struct Ctl {
     uint32_t n_class[8];
     uint32_t n_shadow;
     uint32_t n_gather;
+    uint32_t nf_shadow;   // a NEE request of this bounce carries a non-finite throughput (see k_shade)
+    uint32_t pad_;
     unsigned long long work[4];  // extend, shade, connect, gather
     unsigned long long tot_closest, tot_any;
     unsigned long long work_x[3][8][16];  // [extend|connect|gather][XCD shard], one 128-B line each
@@ -175,6 +177,7 @@ __global__ void k_ctl_reset(Ctl* ctl, int cur, int first, uint32_t first_count, 
     for (int i = 0; i < 8; i++) ctl->n_class[i] = 0;
     ctl->n_shadow = 0;
     ctl->n_gather = 0;
+    ctl->nf_shadow = 0;
     for (int i = 0; i < 4; i++) ctl->work[i] = 0;
     for (int k = 0; k < 3; k++) for (int i = 0; i < 8; i++) ctl->work_x[k][i][0] = 0;
 }
@@ -338,6 +341,11 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_OCC) void k_shade(DScene S
             Shading sd = shading_data(S, o, d, hh.x, hh.y, hh.z, __float_as_uint(hh.w));
             const DMaterial& m = S.mats[sd.mat];
             const bool specular = (m.flags & RT_MF_SPECULAR) != 0;
+            // Upstream always forms pathThroughput * computeDirect(...) (Renderer.h:233), and computeDirect returns
+            // Colour(0) for specular hits, G <= 0 and occluded samples: a channel of T that is inf/NaN (the rough
+            // dielectric's half-vector draw, Materials.h:571, produces them) then turns the pixel NaN whatever the
+            // light sample does.  nfb = those channels; 0 for every ordinary path.
+            const uint32_t nfb = ((T.r - T.r) != 0.0f ? 1u : 0u) | ((T.g - T.g) != 0.0f ? 2u : 0u) | ((T.b - T.b) != 0.0f ? 4u : 0u);
             // --- computeDirect
             if (!specular && S.n_lights > 0) {
                 float pmf = 1.f / S.n_lights;
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_OCC) void k_shade(DScene S
                         want_shadow = true;
                         sh_a = make_float4(sd.x.x, sd.x.y, sd.x.z, __uint_as_float(path));
                         sh_b = make_float4(p.x, p.y, p.z, 0);
-                        sh_c = make_float4(cc.r, cc.g, cc.b, 0);
+                        sh_c = make_float4(cc.r, cc.g, cc.b, __uint_as_float(nfb));
                     }
                 } else if (light.kind == 1) {
                     f3 wi = uniform_sample_sphere(r1, r2);
@@ -374,11 +382,15 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_OCC) void k_shade(DScene S
                         want_shadow = true;
                         sh_a = make_float4(sd.x.x, sd.x.y, sd.x.z, __uint_as_float(path));
                         sh_b = make_float4(p2.x, p2.y, p2.z, 0);
-                        sh_c = make_float4(cc.r, cc.g, cc.b, 0);
+                        sh_c = make_float4(cc.r, cc.g, cc.b, __uint_as_float(nfb));
                     }
                 }
                 // kind 2 (EnvironmentMap::sample): Vec2::operator[] truncates to int upstream (Sampling.h:204), so
                 // wi = (0,1,0) with pdf = inf and the term is 0; the two draws above are still consumed.
+            }
+            if (nfb) {
+                if (want_shadow) atomicOr(&ctl->nf_shadow, 1u);   // k_connect adds T * 0 when the sample is occluded
+                else { float4 L = R.rad[path]; R.rad[path] = make_float4(L.x + T.r * 0.0f, L.y + T.g * 0.0f, L.z + T.b * 0.0f, L.w); }
             }
             if (RADIOSITY && !specular) {
                 want_gather = true;
@@ -417,6 +429,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_OCC) void k_shade(DScene S
 // Scene::visible for every NEE request; visible ones add their (already throughput-weighted) term.
 struct ConnectJob {
     const RBuf& R;
+    const bool nf;   // some request of this launch has a non-finite throughput channel (Ctl::nf_shadow)
     __device__ __forceinline__ bool load(uint32_t i, f3& p1, f3& p2) {
         const float4* e = R.shadow + (size_t)i * 3;
         float4 a = e[0], b = e[1];
@@ -424,8 +437,17 @@ struct ConnectJob {
         return true;
     }
     __device__ __forceinline__ void retire(uint32_t i, const Walk&, bool visible) {
-        if (!visible) return;
         const float4* e = R.shadow + (size_t)i * 3;
+        if (!visible) {
+            if (!nf) return;
+            const uint32_t bits = __float_as_uint(e[2].w);   // occluded: T * Colour(0), NaN in T's non-finite channels
+            if (!bits) return;
+            const uint32_t path = __float_as_uint(e[0].w);
+            const float nan = __uint_as_float(0x7FC00000u);
+            float4 L = R.rad[path];
+            R.rad[path] = make_float4(L.x + ((bits & 1u) ? nan : 0.0f), L.y + ((bits & 2u) ? nan : 0.0f), L.z + ((bits & 4u) ? nan : 0.0f), L.w);
+            return;
+        }
         uint32_t path = __float_as_uint(e[0].w);
         float4 c = e[2];
         float4 L = R.rad[path];
@@ -439,7 +461,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_connect(DScene S, R
     RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
     const uint32_t n = ctl->n_shadow;
     uint32_t cn = 0, ct = 0, cx = 0;
-    ConnectJob job{R};
+    ConnectJob job{R, ctl->nf_shadow != 0};
     XcdSource src; src.xf.init(n); src.w = ctl->work_x[1]; src.n = n;
     rt_persistent_walk<true, COUNT>(S, job, src, 0, st, spill2 + gtid, gstride, cn, ct, cx, counters);
     if (COUNT) {
