@@ -734,7 +734,10 @@ __device__ inline void light_emit(const DScene& S, Rng& rng, float N_vpl, bool f
     ok = true;
 }
 
-__global__ __launch_bounds__(256) void k_lt_generate(DScene S, RBuf R, Ctl* ctl, uint32_t n, uint32_t npix, uint64_t seed, uint64_t first_sample) {
+// Queue appends are block-wide (one atomic per 512 paths): a per-wave atomic on one counter caps a kernel at ~6 G items/s.
+#define RT_LT_BLOCK 512
+__global__ __launch_bounds__(RT_LT_BLOCK) void k_lt_generate(DScene S, RBuf R, Ctl* ctl, uint32_t n, uint32_t npix, uint64_t seed, uint64_t first_sample) {
+    __shared__ uint32_t s_app[RT_LT_BLOCK / 64 + 1];
     for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
         uint32_t i = base + threadIdx.x;
         bool ok = false;
@@ -750,19 +753,30 @@ __global__ __launch_bounds__(256) void k_lt_generate(DScene S, RBuf R, Ctl* ctl,
                 R.rad[i] = make_float4(Le.r, Le.g, Le.b, 0);
             } else R.thr[i] = make_float4(0, 0, 0, __uint_as_float(RT_FLAG_DEAD));
         }
-        uint32_t s1 = wave_append(&ctl->n_shadow, ok);
-        if (ok) { float4* e = R.shadow + (size_t)s1 * 3; e[0] = make_float4(p.x, p.y, p.z, 0); e[1] = make_float4(0, 0, 0, 0); e[2] = make_float4(Le.r, Le.g, Le.b, 0); }
+        // connectToCamera returns before Scene::visible when the point projects outside the film (Renderer.h:672): no request
+        float px_, py_;
+        const bool cam = ok && camera_project(S.cam, p, px_, py_);
+        uint32_t* const counters[1] = { &ctl->n_shadow };
+        const bool pred[1] = { cam };
+        uint32_t slot[1];
+        block_append<1, RT_LT_BLOCK / 64>(counters, pred, slot, s_app);
+        const uint32_t s1 = slot[0];
+        if (cam) { float4* e = R.shadow + (size_t)s1 * 3; e[0] = make_float4(p.x, p.y, p.z, 0); e[1] = make_float4(0, 0, 0, 0); e[2] = make_float4(Le.r, Le.g, Le.b, 0); }
     }
 }
 
 // lightTracePath (Renderer.h:722-767)
-__global__ __launch_bounds__(256) void k_lt_shade(DScene S, RBuf R, Ctl* ctl, int cur) {
+__global__ __launch_bounds__(RT_LT_BLOCK) void k_lt_shade(DScene S, RBuf R, Ctl* ctl, int cur) {
+    __shared__ unsigned long long s_base;
+    __shared__ uint32_t s_app[2 * (RT_LT_BLOCK / 64 + 1)];
     const uint32_t total = ctl->n_class[0];
     for (;;) {
-        unsigned long long base = fetch_chunk(&ctl->work[1]);
+        if (threadIdx.x == 0) s_base = atomicAdd(&ctl->work[1], (unsigned long long)RT_LT_BLOCK);
+        __syncthreads();
+        unsigned long long base = s_base;
         if (base >= total) break;
-        uint32_t g = (uint32_t)base + (threadIdx.x & 63);
-        bool live = g < total, want_next = false;
+        uint32_t g = (uint32_t)base + threadIdx.x;
+        bool live = g < total, want_next = false, cam = false;
         uint32_t path = 0;
         float4 sh_a, sh_c;
         if (live) {
@@ -778,6 +792,8 @@ __global__ __launch_bounds__(256) void k_lt_shade(DScene S, RBuf R, Ctl* ctl, in
             col3 c = (T * bsdf_eval(S, sd, wc)) * Le;
             sh_a = make_float4(sd.x.x, sd.x.y, sd.x.z, 0);
             sh_c = make_float4(c.r, c.g, c.b, 0);
+            float px_, py_;
+            cam = camera_project(S.cam, sd.x, px_, py_);   // off-film points never reach Scene::visible (Renderer.h:672)
             if (!(m.flags & RT_MF_LIGHT) && !(depth > RT_MAX_DEPTH)) {
                 float lum = lumc(T);
                 float rr = lum < 0.9f ? lum : 0.9f;
@@ -797,10 +813,12 @@ __global__ __launch_bounds__(256) void k_lt_shade(DScene S, RBuf R, Ctl* ctl, in
                 }
             }
         }
-        uint32_t s1 = wave_append(&ctl->n_shadow, live);
-        if (live) { float4* e = R.shadow + (size_t)s1 * 3; e[0] = sh_a; e[1] = make_float4(0, 0, 0, 0); e[2] = sh_c; }
-        uint32_t s3 = wave_append(&ctl->n_active[cur ^ 1], want_next);
-        if (want_next) R.q_active[cur ^ 1][s3] = path;
+        uint32_t* const counters[2] = { &ctl->n_shadow, &ctl->n_active[cur ^ 1] };
+        const bool pred[2] = { cam, want_next };
+        uint32_t slot[2];
+        block_append<2, RT_LT_BLOCK / 64>(counters, pred, slot, s_app);   // its barriers also fence s_base for the next round
+        if (cam) { float4* e = R.shadow + (size_t)slot[0] * 3; e[0] = sh_a; e[1] = make_float4(0, 0, 0, 0); e[2] = sh_c; }
+        if (want_next) R.q_active[cur ^ 1][slot[1]] = path;
     }
 }
 
@@ -1177,14 +1195,14 @@ static int render_light(rt_renderer* r, uint32_t batch, uint64_t seed, uint64_t 
     const uint32_t npix = (uint32_t)r->W * r->H;
     const uint32_t n = npix * batch;  // W*H light paths per spp (Renderer.h:331-337)
     LAUNCH(k_ctl_reset, 1, 1, r->ctl, 0, 1, 0u, 0u);
-    LAUNCHK(RT_KID_GENERATE, k_lt_generate, r->flat_blocks, 256, S, R, r->ctl, n, npix, seed, first_sample);
+    LAUNCHK(RT_KID_GENERATE, k_lt_generate, r->flat_blocks / 2, RT_LT_BLOCK, S, R, r->ctl, n, npix, seed, first_sample);
     LAUNCHK(RT_KID_CONNECT, k_connect_camera, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->spill4, r->spill2, r->counters);
     for (int b = 0; b < RT_MAX_DEPTH + 2; b++) {
         int cur = b & 1;
         LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n, n);
         LAUNCHK(RT_KID_EXTEND, (k_extend<true, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
         LAUNCH(k_bin, r->flat_blocks / 2, RT_BIN_BLOCK, R, r->ctl, cur, b == 0 ? 1 : 0);
-        LAUNCHK(RT_KID_SHADE, k_lt_shade, r->flat_blocks, 256, S, R, r->ctl, cur);
+        LAUNCHK(RT_KID_SHADE, k_lt_shade, r->flat_blocks / 2, RT_LT_BLOCK, S, R, r->ctl, cur);
         LAUNCHK(RT_KID_CONNECT, k_connect_camera, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->spill4, r->spill2, r->counters);
     }
     LAUNCH(k_ctl_final, 1, 1, r->ctl);

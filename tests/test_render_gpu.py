@@ -131,6 +131,21 @@ def test_specular_scene_matches_cpu_render_to_its_noise_floor():
     assert abs(g1.mean() / ref.mean() - 1) < 0.02 and abs(g2.mean() / ref.mean() - 1) < 0.02
 
 
+def test_full_size_light_tracing_same_seed():
+    """Light tracing on the bathroom-class 1080p frame: most light vertices project outside the film, where upstream's
+    connectToCamera returns before Scene::visible (Renderer.h:672) - the any-hit ray count must be the oracle's."""
+    s = scenes.bathroom(1.0, 1920, 1080)
+    want, st = orc.OracleScene(s).render(1, 1, seed=3, threads=16)
+    sc = api.Scene(s, device_build=True)
+    rt = api.RayTracer(sc); rt.render(api.LIGHT, 1, 3, 0); got, _ = rt.film(); cnt = rt.counters(); rt.close(); sc.close()
+    assert abs(cnt["closest_rays"] / st["closest_rays"] - 1) < 1e-5 and abs(cnt["any_rays"] / st["any_rays"] - 1) < 1e-5
+    assert np.array_equal(np.isfinite(got), np.isfinite(want))
+    fin = np.isfinite(want).all(axis=2) & np.isfinite(got).all(axis=2)
+    a, b = got[fin].astype(np.float64), want[fin].astype(np.float64)
+    close = (np.abs(a - b) <= 1e-3 * np.maximum(np.abs(a), np.abs(b)) + 1e-4).all(axis=1)
+    assert close.mean() > 0.9995 and abs(a.sum() / b.sum() - 1) < 1e-3
+
+
 @pytest.mark.parametrize("mode", [api.AOV_ALBEDO, api.AOV_NORMAL, api.DIRECT])
 def test_aov_and_direct_passes(mode):
     s = scenes.interior("bathroom", 0.1, 160, 90)

@@ -30,7 +30,7 @@ def run(name, mode, spp, vpls=0):
 
 
 run("path tracing (type 0)", api.PATH, 32)
-run("light tracing (type 1)", api.LIGHT, 8)
+run("light tracing (type 1)", api.LIGHT, 32)
 run("instant radiosity, 50 VPLs (type 4)", api.RADIOSITY, 2, vpls=50)
 run("instant radiosity, 1024 VPLs", api.RADIOSITY, 1, vpls=1024)
 run("PSSMLT (type 2), 100k proposals/spp", api.MLT, 64)
