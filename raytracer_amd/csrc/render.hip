@@ -539,14 +539,14 @@ __global__ __launch_bounds__(256) void k_accumulate(RBuf R, float* film, uint32_
 // vector), and pathTrace draws from PSSSampler::random, so every proposal is a fresh uniform (x, y) plus an
 // independent path.  That makes one spp = 100 paths for b + 1 initial state + 100 000 proposals that can all be
 // traced at once by the wavefront path tracer, followed by upstream's sequential accept/splat loop over their
-// radiances -- one chain per spp, one lane per chain.  Path p = index * n_chains + chain (coalesced for the chain
-// lanes); numbers: stream 2 / pixel = index for the path, stream 4 for the chain's two draws per proposal.
+// radiances -- one chain per spp, one wave per chain (k_mlt_chain).  Path p = chain * RT_MLT_PATHS + index (a wave reads
+// 64 consecutive proposals); numbers: stream 2 / pixel = index for the path, stream 4 for the chain's two draws per proposal.
 #define RT_MLT_M 100u             // Renderer.h:975
 #define RT_MLT_PROPOSALS 100000u  // Renderer.h:357
 #define RT_MLT_PATHS (RT_MLT_M + 1u + RT_MLT_PROPOSALS)
 __global__ __launch_bounds__(256) void k_mlt_generate(DScene S, RBuf R, uint32_t n, uint32_t chains, uint64_t seed, uint64_t first_sample) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        uint32_t index = i / chains, c = i - index * chains;
+        uint32_t c = i / RT_MLT_PATHS, index = i - c * RT_MLT_PATHS;
         Rng rng; rng.key = rt_rng_key(seed, first_sample + c, index, 2); rng.ctr = 0;
         float x = rt_rng_next(rng) * S.cam.width;   // genPathC / genPathP (Renderer.h:978-992)
         float y = rt_rng_next(rng) * S.cam.height;
@@ -578,39 +578,57 @@ __device__ __forceinline__ void mlt_xy(const DScene& S, uint64_t seed, uint64_t 
     x = rt_rng_next(rng) * S.cam.width;
     y = rt_rng_next(rng) * S.cam.height;
 }
+// The accept/reject loop is sequential only in "which proposal is the current state": a proposal's radiance, film
+// position and the chain's two draws for step i (counter-based: draws 2i and 2i+1 of stream 4) do not depend on it.  A wave
+// therefore takes 64 consecutive steps at once: every lane evaluates its step against the wave's current state, the first
+// accepting lane ends the run that state is valid for, becomes the new state, and the lanes behind it re-evaluate -- one
+// round per accepted proposal instead of one trip through memory, RNG and atomics per step.
 __global__ __launch_bounds__(64) void k_mlt_chain(DScene S, RBuf R, float* film, uint32_t chains, uint64_t seed, uint64_t first_sample) {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t c = blockIdx.x, lane = threadIdx.x;
     if (c >= chains) return;
     const uint64_t sample = first_sample + c;
+    const float4* rad = R.rad + (size_t)c * RT_MLT_PATHS;
     const float largeStepProb = 0.3f;  // Renderer.h:1010
-    float b = 0.0f;                    // getNormalization (Renderer.h:995-1006)
+    float b = 0.0f;                    // getNormalization (Renderer.h:995-1006): summed in index order
+#pragma unroll 10
     for (uint32_t i = 0; i < RT_MLT_M; i++) {
-        float4 L = R.rad[(size_t)i * chains + c];
+        float4 L = rad[i];
         b += lumc(mkc(L.x, L.y, L.z));
     }
     b /= (float)RT_MLT_M;
     if (b <= 0.0f) b = 1.0f;
-    float4 L0 = R.rad[(size_t)RT_MLT_M * chains + c];
-    col3 current = mkc(L0.x, L0.y, L0.z);
+    float4 L0 = rad[RT_MLT_M];
+    col3 current = mkc(L0.x, L0.y, L0.z);   // wave-uniform state
     float cx, cy;
     mlt_xy(S, seed, sample, RT_MLT_M, cx, cy);
-    Rng chain; chain.key = rt_rng_key(seed, sample, 0, 4); chain.ctr = 0;
-    constexpr uint32_t U = 8;  // the proposals' radiances do not depend on the chain: fetch them U at a time
-    for (uint32_t i0 = 0; i0 < RT_MLT_PROPOSALS; i0 += U) {
-        float4 buf[U];
-#pragma unroll
-        for (uint32_t j = 0; j < U; j++) buf[j] = R.rad[(size_t)(RT_MLT_M + 1u + i0 + j) * chains + c];
-#pragma unroll
-        for (uint32_t j = 0; j < U; j++) {
-            bool largeStep = rt_rng_next(chain) < largeStepProb;
-            col3 proposed = mkc(buf[j].x, buf[j].y, buf[j].z);
-            float px, py;
-            mlt_xy(S, seed, sample, RT_MLT_M + 1u + i0 + j, px, py);
-            float a = mlt_acceptance(current, proposed);
+    const uint32_t chain_key = rt_rng_key(seed, sample, 0, 4);
+    for (uint32_t i0 = 0; i0 < RT_MLT_PROPOSALS; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const bool valid = i < RT_MLT_PROPOSALS;
+        float4 L = valid ? rad[RT_MLT_M + 1u + i] : make_float4(0, 0, 0, 0);
+        const col3 proposed = mkc(L.x, L.y, L.z);
+        Rng chain; chain.key = chain_key; chain.ctr = 2u * i;
+        const bool largeStep = rt_rng_next(chain) < largeStepProb;
+        const float u_accept = rt_rng_next(chain);
+        float px, py;
+        mlt_xy(S, seed, sample, RT_MLT_M + 1u + i, px, py);
+        unsigned long long pending = __ballot(valid);
+        float a = 0.0f, scx = cx, scy = cy;
+        col3 scur = current;   // the state this lane's step sees
+        while (pending) {
+            const float aj = mlt_acceptance(current, proposed);
+            const unsigned long long accept = __ballot(u_accept < aj) & pending;
+            const uint32_t first = accept ? (uint32_t)__ffsll((long long)accept) - 1u : 63u;
+            if (((pending >> lane) & 1ULL) && lane <= first) { a = aj; scur = current; scx = cx; scy = cy; }
+            if (!accept) break;
+            current = mkc(__shfl(proposed.r, first), __shfl(proposed.g, first), __shfl(proposed.b, first));
+            cx = __shfl(px, first); cy = __shfl(py, first);
+            pending = first == 63u ? 0ULL : (pending & ~((2ULL << first) - 1ULL));
+        }
+        if (valid) {
             if (largeStep) film_splat(film, S.cam, px, py, (proposed * a) / (b + largeStepProb * lumc(proposed)));
             else film_splat(film, S.cam, px, py, (proposed * a) / b);
-            film_splat(film, S.cam, cx, cy, (current * (1.0f - a)) / b);
-            if (rt_rng_next(chain) < a) { current = proposed; cx = px; cy = py; }
+            film_splat(film, S.cam, scx, scy, (scur * (1.0f - a)) / b);
         }
     }
 }
@@ -1227,7 +1245,7 @@ static int render_mlt(rt_renderer* r, uint32_t chains, uint64_t seed, uint64_t f
         LAUNCHK(RT_KID_CONNECT, k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
     }
     LAUNCH(k_ctl_final, 1, 1, r->ctl);
-    LAUNCHK(RT_KID_ACCUMULATE, k_mlt_chain, (chains + 63) / 64, 64, S, R, r->film, chains, seed, first_sample);
+    LAUNCHK(RT_KID_ACCUMULATE, k_mlt_chain, chains, 64, S, R, r->film, chains, seed, first_sample);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }
