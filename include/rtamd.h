@@ -161,6 +161,15 @@ void rt_renderer_destroy(rt_renderer* r);
 /* Adds `spp` samples per pixel (sample indices first_sample .. first_sample+spp-1 of RNG stream `seed`)
  * to the film and increments SPP by spp: `spp` consecutive RayTracer::render() calls. */
 int rt_render(rt_renderer* r, int mode, int spp, uint64_t seed, uint64_t first_sample);
+/* The film's ImageFilter for later rt_render calls: what `film->init(w, h, new BoxFilter())` (Renderer.h:61)
+ * chooses upstream.  Film::splat (Imaging.h:224-247) spreads every sample over (2 size + 1)^2 pixels with
+ * weights filter(px - x, py - y) / sum.  The AOV and direct passes keep their BoxFilter (Renderer.h:100-103). */
+enum {
+    RT_FILTER_BOX = 0,       /* BoxFilter, size 0 (Imaging.h:138): the default */
+    RT_FILTER_GAUSSIAN = 1,  /* GaussianFilter, size 1 (Imaging.h:159) */
+    RT_FILTER_MITCHELL = 2   /* MitchellNetravaliFilter, size 2 (Imaging.h:179) */
+};
+int rt_renderer_set_filter(rt_renderer* r, int filter);
 int rt_film_clear(rt_renderer* r);                                        /* RayTracer::clear (Renderer.h:107) */
 int rt_film_spp(const rt_renderer* r);                                    /* RayTracer::getSPP (Renderer.h:652) */
 /* Un-normalised accumulation film (Film::film, Imaging.h:219) + SPP; rgb = width*height*3 floats. */

@@ -55,6 +55,10 @@ def lib():
         L.orc_vpl_count.argtypes = [C.c_void_p]
         L.orc_vpl_count.restype = C.c_int
         L.orc_vpl_get.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_set_filter.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_filter.restype = None
+        L.orc_filter_eval.argtypes = [C.c_int, C.c_float, C.c_float]
+        L.orc_filter_eval.restype = C.c_float
         L.orc_bsdf_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_bsdf_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_rng_floats.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
@@ -100,6 +104,10 @@ class OracleScene:
             self.close()
         except Exception:
             pass
+
+    def set_filter(self, kind):
+        """film->init(w, h, new BoxFilter / GaussianFilter / MitchellNetravaliFilter) (Renderer.h:61): 0 / 1 / 2."""
+        self.L.orc_set_filter(self.h, kind)
 
     def info(self):
         st = np.zeros(5, np.int32)

@@ -271,6 +271,7 @@ struct orc_scene {
     float width, height;
     V3 origin, view_dir; float Afilm;
     VPL* vpls; int nvpls, cap_vpls;
+    int filter; /* 0 BoxFilter (Renderer.h:61), 1 GaussianFilter, 2 MitchellNetravaliFilter */
 };
 
 /* ---------------------------------------------------------------- BVH build (ref: Geometry.h:310-438) */
@@ -1057,17 +1058,57 @@ static Col path_trace(Ctx* c, V3 o, V3 dir, Rng* rng, int radiosity) {
     return L;
 }
 
-static void film_add(float* film, int W, int H, float x, float y, Col L, int atomic) { /* Film::splat with BoxFilter, Imaging.h:224 */
-    int px = (int)x, py = (int)y;
-    if (!(px >= 0 && px < W && py >= 0 && py < H)) return;
-    float* p = film + ((size_t)py * W + px) * 3;
-    float v[3] = { L.r, L.g, L.b };
-    for (int k = 0; k < 3; k++) {
-        if (!atomic) { p[k] = p[k] + v[k]; continue; }
-        _Atomic uint32_t* a = (_Atomic uint32_t*)&p[k];
-        uint32_t old = atomic_load_explicit(a, memory_order_relaxed), nw;
-        do { float fo; memcpy(&fo, &old, 4); float fn = fo + v[k]; memcpy(&nw, &fn, 4); }
-        while (!atomic_compare_exchange_weak_explicit(a, &old, nw, memory_order_relaxed, memory_order_relaxed));
+/* ImageFilter::filter / size (Imaging.h:138-214).  The C++ promotions are kept: pow(int, int) and pow(float, int) are
+ * double, the products with the float constants are double, the functions return float. */
+static float filter_gauss1(int d) { /* GaussianFilter::gauss(int d, int radius): the float offsets arrive truncated to int */
+    float Nalpha = -1.f, radius = 1.f;                                     /* Imaging.h:155-156 (globals) */
+    float secondPart = (float)exp((double)Nalpha * pow((double)radius, 2)); /* Imaging.h:158 */
+    return (float)(exp((double)Nalpha * pow((double)d, 2)) - (double)secondPart);
+}
+static float filter_mn1(float y) { /* MitchellNetravaliFilter::MN, Imaging.h:193-205 */
+    float B = 1.f / 3.f, C = 1.f / 3.f;
+    float a1 = 12 - (9 * B) - (6 * C), b1 = -18 + (12 * B) + (6 * C), c1 = 6 - (2 * B);
+    float a2 = (-B) - (6 * C), b2 = (6 * B) + (30 * C), c2 = -(12 * B) - (48 * C), d2 = (8 * B) - (24 * C);
+    float x = fabsf(y);
+    if (fabsf(x) <= 0.0f && fabs(x) < 1.0f) return (float)((((double)a1 * pow((double)x, 3)) + ((double)b1 * pow((double)x, 2)) + (double)(c1)) / 6);
+    else if (fabsf(x) <= 1.0f && fabs(x) < 2.0f) return (float)((((double)a2 * pow((double)x, 3)) + ((double)b2 * pow((double)x, 2)) + (double)(c2 * x) + (double)d2) / 6);
+    else if (fabsf(x) >= 2) return 0;
+    return 0; /* 1 < |x| < 2: upstream falls off the end of the function (undefined value); defined here as 0 */
+}
+static float filter_eval(int kind, float x, float y) {
+    if (kind == 1) return filter_gauss1((int)x) * filter_gauss1((int)y);
+    if (kind == 2) return filter_mn1(x) * filter_mn1(y);
+    return (fabsf(x) <= 1.0f && fabs(y) <= 1.0f) ? 1.0f : 0.0f; /* BoxFilter */
+}
+static inline int filter_size(int kind) { return kind == 1 ? 1 : kind == 2 ? 2 : 0; }
+static void film_atomic_add(float* p, float v) {
+    _Atomic uint32_t* a = (_Atomic uint32_t*)p;
+    uint32_t old = atomic_load_explicit(a, memory_order_relaxed), nw;
+    do { float fo; memcpy(&fo, &old, 4); float fn = fo + v; memcpy(&nw, &fn, 4); }
+    while (!atomic_compare_exchange_weak_explicit(a, &old, nw, memory_order_relaxed, memory_order_relaxed));
+}
+/* Film::splat, Imaging.h:224-247.  With the size-0 BoxFilter this is film[(int)y * W + (int)x] += L * 1 / 1. */
+static void film_add(float* film, int W, int H, float x, float y, Col L, int atomic, int filter) {
+    float w[25]; int idx[25]; int used = 0; float total = 0;
+    int size = filter_size(filter);
+    for (int i = -size; i <= size; i++)
+        for (int j = -size; j <= size; j++) {
+            int px = (int)x + j, py = (int)y + i;
+            if (px >= 0 && px < W && py >= 0 && py < H) {
+                idx[used] = (py * W) + px;
+                w[used] = filter ? filter_eval(filter, px - x, py - y) : 1.0f;
+                total += w[used];
+                used++;
+            }
+        }
+    if (filter) atomic = 1; /* footprints of neighbouring pixels overlap across render threads */
+    for (int i = 0; i < used; i++) {
+        float* p = film + (size_t)idx[i] * 3;
+        float v[3] = { filter ? L.r * w[i] / total : L.r, filter ? L.g * w[i] / total : L.g, filter ? L.b * w[i] / total : L.b };
+        for (int k = 0; k < 3; k++) {
+            if (!atomic) p[k] = p[k] + v[k];
+            else film_atomic_add(&p[k], v[k]);
+        }
     }
 }
 
@@ -1080,7 +1121,7 @@ static void connect_to_camera(Ctx* c, V3 p, Col colr, float* film) {
     float ct = vdot(s->view_dir, cd);
     if (ct <= 0) return;
     float we = 1.f / (s->Afilm * pow((double)ct, 4.0));
-    film_add(film, (int)s->width, (int)s->height, x, y, cmulf(colr, we), 1);
+    film_add(film, (int)s->width, (int)s->height, x, y, cmulf(colr, we), 1, s->filter);
 }
 /* Renderer.h:695-767 */
 static void light_trace(Ctx* c, Rng* rng, float* film) {
@@ -1163,6 +1204,8 @@ int orc_vpl_trace(orc_scene* s, int N, uint64_t seed) {
     return s->nvpls;
 }
 int orc_vpl_count(orc_scene* s) { return s->nvpls; }
+void orc_set_filter(orc_scene* s, int kind) { s->filter = (kind == 1 || kind == 2) ? kind : 0; }
+float orc_filter_eval(int kind, float x, float y) { return filter_eval(kind, x, y); }
 void orc_vpl_get(orc_scene* s, float* out) {
     for (int i = 0; i < s->nvpls; i++) {
         const VPL* v = &s->vpls[i];
@@ -1238,9 +1281,9 @@ void orc_mlt_render(orc_scene* s, int spp, uint64_t seed, uint64_t first, float*
             int largeStep = rng_next(&chain) < largeStepProb;
             Col proposed = mlt_path(&c, seed, sample, (uint32_t)(MLT_M + 1 + i), &px, &py);
             float a = mlt_acceptance(current, proposed);
-            if (largeStep) film_add(film, W, H, px, py, cdivf(cmulf(proposed, a), (b + largeStepProb * clum(proposed))), 0);
-            else film_add(film, W, H, px, py, cdivf(cmulf(proposed, a), b), 0);
-            film_add(film, W, H, cx, cy, cdivf(cmulf(current, (1.0f - a)), b), 0);
+            if (largeStep) film_add(film, W, H, px, py, cdivf(cmulf(proposed, a), (b + largeStepProb * clum(proposed))), 0, s->filter);
+            else film_add(film, W, H, px, py, cdivf(cmulf(proposed, a), b), 0, s->filter);
+            film_add(film, W, H, cx, cy, cdivf(cmulf(current, (1.0f - a)), b), 0, s->filter);
             if (rng_next(&chain) < a) { current = proposed; cx = px; cy = py; }
         }
     }
@@ -1276,7 +1319,7 @@ static void render_pixel(Job* j, int x, int y) {
             camera_ray(s, px + u1, py + u2, &o, &d); /* Renderer.h:205 */
             L = path_trace(&j->ctx, o, d, &rng, j->mode == 4);
         }
-        film_add(j->film, W, H, px, py, L, 0); /* Renderer.h:535 */
+        film_add(j->film, W, H, px, py, L, 0, j->mode >= 10 ? 0 : s->filter); /* Renderer.h:535; the AOV films keep their BoxFilter (Renderer.h:100-103) */
     }
 }
 static void* render_worker(void* arg) {

@@ -94,6 +94,8 @@ void orc_render(orc_scene*, int mode, int spp, uint64_t seed, uint64_t first_sam
                 float* film_rgb, int nthreads, orc_stats* stats);
 int  orc_vpl_trace(orc_scene*, int n_vpls, uint64_t seed);
 int  orc_vpl_count(orc_scene*);
+void orc_set_filter(orc_scene*, int kind); /* film filter of later renders: 0 Box, 1 Gaussian, 2 MitchellNetravali (Imaging.h:138-214) */
+float orc_filter_eval(int kind, float x, float y); /* ImageFilter::filter */
 void orc_vpl_get(orc_scene*, float* out /* n*[x3, n3, Le3, mat] = 10 floats */);
 
 /* single-function probes for unit tests */

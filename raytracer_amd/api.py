@@ -20,6 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT_LIB", os.path.join(_HERE, "librtamd.so"))  # RT_LIB: A/B builds of the same HIP library
 
 PATH, LIGHT, MLT, RADIOSITY, PATH_ST, AOV_ALBEDO, AOV_NORMAL, DIRECT = 0, 1, 2, 4, 5, 10, 11, 12
+FILTER_BOX, FILTER_GAUSSIAN, FILTER_MITCHELL = 0, 1, 2  # ImageFilter of the film (Imaging.h:138-214)
 
 
 class RtError(RuntimeError):
@@ -55,6 +56,7 @@ SYMBOLS = [
     "rt_renderer_create", "rt_renderer_destroy", "rt_render", "rt_film_clear", "rt_film_spp", "rt_film_read", "rt_film_bind",
     "rt_film_set_spp", "rt_vpl_trace", "rt_vpl_count", "rt_render_counters", "rt_renderer_sync", "rt_film_save_hdr",
     "rt_film_tonemap", "rt_profile_enable", "rt_profile_read", "rt_debug_bsdf_sample", "rt_debug_bsdf_eval", "rt_debug_rng", "rt_matrix_invert", "rt_scene_create_ex",
+    "rt_renderer_set_filter",
 ]
 
 
@@ -105,6 +107,7 @@ def lib():
         _sig(L, "rt_film_bind", [vp, vp])
         _sig(L, "rt_film_set_spp", [vp, i32])
         _sig(L, "rt_vpl_trace", [vp, i32, u64])
+        _sig(L, "rt_renderer_set_filter", [vp, i32])
         _sig(L, "rt_vpl_count", [vp])
         _sig(L, "rt_render_counters", [vp, C.POINTER(Counters), i32])
         _sig(L, "rt_renderer_sync", [vp])
@@ -280,6 +283,10 @@ class RayTracer:
 
     def set_spp(self, spp):
         _check(self.L.rt_film_set_spp(self.h, spp), "rt_film_set_spp")
+
+    def setFilter(self, kind):
+        """film->init(w, h, new BoxFilter / GaussianFilter / MitchellNetravaliFilter) (Renderer.h:61): FILTER_BOX / _GAUSSIAN / _MITCHELL."""
+        _check(self.L.rt_renderer_set_filter(self.h, kind), "rt_renderer_set_filter")
 
     def traceVPLs(self, n, seed=1):
         _check(self.L.rt_vpl_trace(self.h, n, seed), "rt_vpl_trace")

@@ -473,11 +473,82 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_connect(DScene S, R
     }
 }
 
+// ------------------------------------------------------------------------------------------------ film filters
+// ImageFilter (Imaging.h:131-214) as Film::splat uses it (Imaging.h:224-247): weights over the (2 size + 1)^2 pixels
+// around (int)x, (int)y, normalised by their in-bounds sum.  kind 0 = BoxFilter, size 0: upstream's default
+// (Renderer.h:61) and the fast path everywhere.  The Gaussian receives its offsets truncated to int (gauss(int d, ..)),
+// so it is a table over d; Mitchell-Netravali keeps upstream's branch conditions (the first polynomial only at x == 0,
+// the second for 0 < x <= 1, no value for 1 < x < 2: 0 here) and its double-precision promotions.
+struct DFilter {
+    int kind;
+    float g[4];                            // GaussianFilter::gauss(d) for d = -2, -1, 0, 1
+    float a1, b1, c1, a2, b2, c2, d2;      // MitchellNetravaliFilter coefficients (Imaging.h:185-191)
+    float w[25], wtot;                     // weights at pixel-centre offsets (j - 0.5, i - 0.5), row-major (i, j), and their full sum
+};
+__device__ __forceinline__ float filter_mn(const DFilter& F, float y) {
+    const float x = fabsf(y);
+    const double xd = (double)x;
+    if (x <= 0.0f) return (float)((((double)F.a1 * (xd * xd * xd)) + ((double)F.b1 * (xd * xd)) + (double)F.c1) / 6);
+    if (x <= 1.0f) return (float)((((double)F.a2 * (xd * xd * xd)) + ((double)F.b2 * (xd * xd)) + (double)(F.c2 * x) + (double)F.d2) / 6);
+    return 0.0f;
+}
+__device__ __forceinline__ float filter_1d(const DFilter& F, float x) {   // filter(x, y) = filter_1d(x) * filter_1d(y) for both
+    if (F.kind == 1) {
+        int d = (int)x + 2;   // offsets lie in (-size - 1, size]
+        d = d < 0 ? 0 : (d > 3 ? 3 : d);
+        return F.g[d];
+    }
+    return filter_mn(F, x);
+}
+template <int SIZE>
+__device__ __forceinline__ void film_splat_n(float* film, const DCamera& cam, const DFilter& F, float x, float y, col3 c) {
+    const int bx = (int)x, by = (int)y;
+    float wx[2 * SIZE + 1], wy[2 * SIZE + 1];
+#pragma unroll
+    for (int j = -SIZE; j <= SIZE; j++) { wx[j + SIZE] = filter_1d(F, (float)(bx + j) - x); wy[j + SIZE] = filter_1d(F, (float)(by + j) - y); }
+    float total = 0.0f;
+#pragma unroll
+    for (int i = -SIZE; i <= SIZE; i++)
+#pragma unroll
+        for (int j = -SIZE; j <= SIZE; j++) {
+            const int px = bx + j, py = by + i;
+            if (px >= 0 && px < cam.iw && py >= 0 && py < cam.ih) total += wx[j + SIZE] * wy[i + SIZE];
+        }
+#pragma unroll
+    for (int i = -SIZE; i <= SIZE; i++)
+#pragma unroll
+        for (int j = -SIZE; j <= SIZE; j++) {
+            const int px = bx + j, py = by + i;
+            if (px >= 0 && px < cam.iw && py >= 0 && py < cam.ih) {
+                const float w = wx[j + SIZE] * wy[i + SIZE];
+                float* f = film + ((size_t)py * cam.iw + px) * 3;
+                const float vr = (c.r * w) / total, vg = (c.g * w) / total, vb = (c.b * w) / total;
+                // adding +-0 changes nothing (most Mitchell-Netravali weights are exactly 0); NaN != 0, so those still land
+                if (vr != 0.0f) atomicAdd(f + 0, vr);
+                if (vg != 0.0f) atomicAdd(f + 1, vg);
+                if (vb != 0.0f) atomicAdd(f + 2, vb);
+            }
+        }
+}
+// Film::splat with float atomics (light tracing, PSSMLT)
+__device__ __forceinline__ void film_splat(float* film, const DCamera& cam, const DFilter& F, float x, float y, col3 c) {
+    if (F.kind == 0) {
+        const int bx = (int)x, by = (int)y;
+        if (bx >= 0 && bx < cam.iw && by >= 0 && by < cam.ih) {
+            float* f = film + ((size_t)by * cam.iw + bx) * 3;
+            atomicAdd(f + 0, c.r); atomicAdd(f + 1, c.g); atomicAdd(f + 2, c.b);
+        }
+    } else if (F.kind == 1) film_splat_n<1>(film, cam, F, x, y, c);
+    else film_splat_n<2>(film, cam, F, x, y, c);
+}
+
 // connectToCamera (Renderer.h:669-692): projection, visibility to the lens, We = 1/(Afilm cos^4), atomic splat
+template <bool FILTERED>   // false: BoxFilter only (the filter code stays out of the persistent kernel's register budget)
 struct CameraJob {
     const DScene& S;
     const RBuf& R;
     float* film;
+    const DFilter& F;
     __device__ __forceinline__ bool load(uint32_t i, f3& p1, f3& p2) {
         float4 a = R.shadow[(size_t)i * 3];
         float x, y;
@@ -499,6 +570,7 @@ struct CameraJob {
         if (costheta <= 0) return;
         float we = (float)(1.f / (cam.Afilm * pow((double)costheta, 4.0)));
         float4 c = e[2];
+        if (FILTERED) { film_splat(film, cam, F, x, y, mkc(c.x * we, c.y * we, c.z * we)); return; }
         int px = (int)x, py = (int)y;  // Film::splat with BoxFilter (Imaging.h:224)
         if (px >= 0 && px < cam.iw && py >= 0 && py < cam.ih) {
             float* f = film + ((size_t)py * cam.iw + px) * 3;
@@ -506,13 +578,14 @@ struct CameraJob {
         }
     }
 };
-__global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_connect_camera(DScene S, RBuf R, Ctl* ctl, float* film, uint32_t* spill4, uint32_t* spill2, DCounters* counters) {
+template <bool FILTERED>
+__global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_connect_camera(DScene S, RBuf R, Ctl* ctl, float* film, DFilter F, uint32_t* spill4, uint32_t* spill2, DCounters* counters) {
     __shared__ uint32_t lds_stack[RT_STACK_WORDS];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
     RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
     const uint32_t n = ctl->n_shadow;
     uint32_t cn = 0, ct = 0, cx = 0;
-    CameraJob job{S, R, film};
+    CameraJob<FILTERED> job{S, R, film, F};
     XcdSource src; src.xf.init(n); src.w = ctl->work_x[1]; src.n = n;
     rt_persistent_walk<true, false>(S, job, src, 0, st, spill2 + gtid, gstride, cn, ct, cx, counters);
 }
@@ -529,6 +602,41 @@ __global__ __launch_bounds__(256) void k_accumulate(RBuf R, float* film, uint32_
             float4 L = R.rad[(size_t)s * R.np_pad + q];
             r = r + L.x; g = g + L.y; b = b + L.z;
         }
+        f[0] = r; f[1] = g; f[2] = b;
+    }
+}
+
+// The same with a Gaussian / Mitchell-Netravali film: every sample is splatted at its pixel centre (Renderer.h:527-535), so
+// the weights are one (2 size + 1)^2 table, and a pixel can gather what its neighbours' samples give it -- no atomics, fixed
+// order.  A source pixel near the border divides by the sum of its in-bounds weights, in upstream's loop order.
+__global__ __launch_bounds__(256) void k_accumulate_filtered(RBuf R, float* film, uint32_t batch, DFilter F) {
+    const int size = F.kind == 1 ? 1 : 2, span = 2 * size + 1;
+    const int W = (int)R.w, H = (int)R.h;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < R.np_pad; q += gridDim.x * blockDim.x) {
+        uint32_t x, y;
+        if (!slot_pixel(R, q, x, y)) continue;
+        float* f = film + ((size_t)y * R.w + x) * 3;
+        float r = f[0], g = f[1], b = f[2];
+        for (int i = -size; i <= size; i++)
+            for (int j = -size; j <= size; j++) {
+                const int sx = (int)x - j, sy = (int)y - i;   // the source whose footprint offset (j, i) lands here
+                if (sx < 0 || sx >= W || sy < 0 || sy >= H) continue;
+                const float w = F.w[(i + size) * span + (j + size)];
+                float total = F.wtot;
+                if (sx < size || sx + size >= W || sy < size || sy + size >= H) {
+                    total = 0.0f;
+                    for (int i2 = -size; i2 <= size; i2++)
+                        for (int j2 = -size; j2 <= size; j2++) {
+                            const int px = sx + j2, py = sy + i2;
+                            if (px >= 0 && px < W && py >= 0 && py < H) total += F.w[(i2 + size) * span + (j2 + size)];
+                        }
+                }
+                const uint32_t sq = (((uint32_t)sy >> 3) * R.tiles_x + ((uint32_t)sx >> 3)) * 64u + (((uint32_t)sy & 7u) << 3) + ((uint32_t)sx & 7u);
+                for (uint32_t s = 0; s < batch; s++) {
+                    float4 L = R.rad[(size_t)s * R.np_pad + sq];
+                    r = r + (L.x * w) / total; g = g + (L.y * w) / total; b = b + (L.z * w) / total;
+                }
+            }
         f[0] = r; f[1] = g; f[2] = b;
     }
 }
@@ -566,13 +674,6 @@ __device__ __forceinline__ float mlt_acceptance(col3 current, col3 proposed) {  
     float r = pl / cl;
     return (r < 1.0f) ? r : 1.0f;  // (std::min)(1.0f, r)
 }
-__device__ __forceinline__ void film_splat(float* film, const DCamera& cam, float x, float y, col3 c) {  // Film::splat, BoxFilter (Imaging.h:224)
-    int px = (int)x, py = (int)y;
-    if (px >= 0 && px < cam.iw && py >= 0 && py < cam.ih) {
-        float* f = film + ((size_t)py * cam.iw + px) * 3;
-        atomicAdd(f + 0, c.r); atomicAdd(f + 1, c.g); atomicAdd(f + 2, c.b);
-    }
-}
 __device__ __forceinline__ void mlt_xy(const DScene& S, uint64_t seed, uint64_t sample, uint32_t index, float& x, float& y) {
     Rng rng; rng.key = rt_rng_key(seed, sample, index, 2); rng.ctr = 0;
     x = rt_rng_next(rng) * S.cam.width;
@@ -583,7 +684,7 @@ __device__ __forceinline__ void mlt_xy(const DScene& S, uint64_t seed, uint64_t 
 // therefore takes 64 consecutive steps at once: every lane evaluates its step against the wave's current state, the first
 // accepting lane ends the run that state is valid for, becomes the new state, and the lanes behind it re-evaluate -- one
 // round per accepted proposal instead of one trip through memory, RNG and atomics per step.
-__global__ __launch_bounds__(64) void k_mlt_chain(DScene S, RBuf R, float* film, uint32_t chains, uint64_t seed, uint64_t first_sample) {
+__global__ __launch_bounds__(64) void k_mlt_chain(DScene S, RBuf R, float* film, DFilter F, uint32_t chains, uint64_t seed, uint64_t first_sample) {
     const uint32_t c = blockIdx.x, lane = threadIdx.x;
     if (c >= chains) return;
     const uint64_t sample = first_sample + c;
@@ -626,9 +727,9 @@ __global__ __launch_bounds__(64) void k_mlt_chain(DScene S, RBuf R, float* film,
             pending = first == 63u ? 0ULL : (pending & ~((2ULL << first) - 1ULL));
         }
         if (valid) {
-            if (largeStep) film_splat(film, S.cam, px, py, (proposed * a) / (b + largeStepProb * lumc(proposed)));
-            else film_splat(film, S.cam, px, py, (proposed * a) / b);
-            film_splat(film, S.cam, scx, scy, (scur * (1.0f - a)) / b);
+            if (largeStep) film_splat(film, S.cam, F, px, py, (proposed * a) / (b + largeStepProb * lumc(proposed)));
+            else film_splat(film, S.cam, F, px, py, (proposed * a) / b);
+            film_splat(film, S.cam, F, scx, scy, (scur * (1.0f - a)) / b);
         }
     }
 }
@@ -1006,6 +1107,7 @@ struct rt_renderer {
     float* film_own = nullptr;
     float* film = nullptr;
     int spp = 0;
+    DFilter filter{};   // kind 0 (BoxFilter) until rt_renderer_set_filter
     uint32_t batch_max = 1;
     uint32_t* spill4 = nullptr;
     uint32_t* spill2 = nullptr;
@@ -1091,6 +1193,44 @@ static int ensure_other_lane(rt_renderer* r) {
     if ((rc = dev_alloc(r, &o.spill2, threads * std::max<uint32_t>(h.max_stack2, 2)))) return rc;
     RT_HIP(hipMemsetAsync(o.ctl, 0, sizeof(Ctl), o.stream));
     r->other_ready = true;
+    return RT_OK;
+}
+
+// ImageFilter tables, host side: the same expressions and promotions as Imaging.h:155-214 (see DFilter).
+static float host_gauss1(int d) {
+    float Nalpha = -1.f, radius = 1.f;
+    float secondPart = (float)std::exp((double)Nalpha * std::pow((double)radius, 2));
+    return (float)(std::exp((double)Nalpha * std::pow((double)d, 2)) - (double)secondPart);
+}
+static float host_mn1(const DFilter& F, float y) {
+    float x = std::fabs(y);
+    if (x <= 0.0f) return (float)((((double)F.a1 * std::pow((double)x, 3)) + ((double)F.b1 * std::pow((double)x, 2)) + (double)F.c1) / 6);
+    if (x <= 1.0f) return (float)((((double)F.a2 * std::pow((double)x, 3)) + ((double)F.b2 * std::pow((double)x, 2)) + (double)(F.c2 * x) + (double)F.d2) / 6);
+    return 0.0f;   // >= 2: 0 upstream; 1 < x < 2: no return statement upstream, 0 here
+}
+extern "C" int rt_renderer_set_filter(rt_renderer* r, int kind) {
+    if (!r) { rt_set_error("rt_renderer_set_filter: NULL renderer"); return RT_ERR_INVALID; }
+    if (kind != RT_FILTER_BOX && kind != RT_FILTER_GAUSSIAN && kind != RT_FILTER_MITCHELL) {
+        rt_set_error("rt_renderer_set_filter: unknown filter"); return RT_ERR_INVALID;
+    }
+    DFilter F{};
+    F.kind = kind;
+    for (int d = -2; d <= 1; d++) F.g[d + 2] = host_gauss1(d);
+    const float B = 1.f / 3.f, C = 1.f / 3.f;
+    F.a1 = 12 - (9 * B) - (6 * C); F.b1 = -18 + (12 * B) + (6 * C); F.c1 = 6 - (2 * B);
+    F.a2 = (-B) - (6 * C); F.b2 = (6 * B) + (30 * C); F.c2 = -(12 * B) - (48 * C); F.d2 = (8 * B) - (24 * C);
+    const int size = kind == RT_FILTER_GAUSSIAN ? 1 : kind == RT_FILTER_MITCHELL ? 2 : 0, span = 2 * size + 1;
+    F.wtot = 0.0f;
+    for (int i = -size; i <= size; i++)
+        for (int j = -size; j <= size; j++) {
+            const float dx = (float)j - 0.5f, dy = (float)i - 0.5f;   // px - x for x = pixel + 0.5 (Renderer.h:527)
+            float w = 1.0f;
+            if (kind == RT_FILTER_GAUSSIAN) w = host_gauss1((int)dx) * host_gauss1((int)dy);
+            else if (kind == RT_FILTER_MITCHELL) w = host_mn1(F, dx) * host_mn1(F, dy);
+            F.w[(i + size) * span + (j + size)] = w;
+            F.wtot += w;
+        }
+    r->filter = F;
     return RT_OK;
 }
 
@@ -1190,7 +1330,8 @@ static int render_path_like(rt_renderer* r, int mode, uint32_t batch, uint64_t s
     }
     LAUNCH(k_ctl_final, 1, 1, r->ctl);
     if (r->acc_pending) RT_HIP(hipStreamWaitEvent(r->stream, r->acc_event, 0));   // film += in batch order, whichever lane ran the batch
-    LAUNCHK(RT_KID_ACCUMULATE, k_accumulate, r->flat_blocks, 256, R, r->film, batch);
+    if (r->filter.kind) LAUNCHK(RT_KID_ACCUMULATE, k_accumulate_filtered, r->flat_blocks, 256, R, r->film, batch, r->filter);
+    else LAUNCHK(RT_KID_ACCUMULATE, k_accumulate, r->flat_blocks, 256, R, r->film, batch);
     RT_HIP(hipEventRecord(r->acc_event, r->stream));
     r->acc_pending = true;
     RT_HIP(hipGetLastError());
@@ -1217,14 +1358,16 @@ static int render_light(rt_renderer* r, uint32_t batch, uint64_t seed, uint64_t 
     const uint32_t n = npix * batch;  // W*H light paths per spp (Renderer.h:331-337)
     LAUNCH(k_ctl_reset, 1, 1, r->ctl, 0, 1, 0u, 0u);
     LAUNCHK(RT_KID_GENERATE, k_lt_generate, r->flat_blocks / 2, RT_LT_BLOCK, S, R, r->ctl, n, npix, seed, first_sample);
-    LAUNCHK(RT_KID_CONNECT, k_connect_camera, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->spill4, r->spill2, r->counters);
+    if (r->filter.kind) LAUNCHK(RT_KID_CONNECT, k_connect_camera<true>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->filter, r->spill4, r->spill2, r->counters);
+    else LAUNCHK(RT_KID_CONNECT, k_connect_camera<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->filter, r->spill4, r->spill2, r->counters);
     for (int b = 0; b < RT_MAX_DEPTH + 2; b++) {
         int cur = b & 1;
         LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n, n);
         LAUNCHK(RT_KID_EXTEND, (k_extend<true, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
         LAUNCH(k_bin, r->flat_blocks / 2, RT_BIN_BLOCK, R, r->ctl, cur, b == 0 ? 1 : 0);
         LAUNCHK(RT_KID_SHADE, k_lt_shade, r->flat_blocks / 2, RT_LT_BLOCK, S, R, r->ctl, cur);
-        LAUNCHK(RT_KID_CONNECT, k_connect_camera, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->spill4, r->spill2, r->counters);
+        if (r->filter.kind) LAUNCHK(RT_KID_CONNECT, k_connect_camera<true>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->filter, r->spill4, r->spill2, r->counters);
+        else LAUNCHK(RT_KID_CONNECT, k_connect_camera<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->filter, r->spill4, r->spill2, r->counters);
     }
     LAUNCH(k_ctl_final, 1, 1, r->ctl);
     RT_HIP(hipGetLastError());
@@ -1245,7 +1388,7 @@ static int render_mlt(rt_renderer* r, uint32_t chains, uint64_t seed, uint64_t f
         LAUNCHK(RT_KID_CONNECT, k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
     }
     LAUNCH(k_ctl_final, 1, 1, r->ctl);
-    LAUNCHK(RT_KID_ACCUMULATE, k_mlt_chain, chains, 64, S, R, r->film, chains, seed, first_sample);
+    LAUNCHK(RT_KID_ACCUMULATE, k_mlt_chain, chains, 64, S, R, r->film, r->filter, chains, seed, first_sample);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }

@@ -2,6 +2,7 @@
 // (render() until getSPP() == SPP, print the seconds each call took, then saveHDR; Main.cpp:79-137), no window.
 // Extra arguments: -type (RayTracer::type, Renderer.h:372), -width/-height (built-in cornell-box only), -seed,
 // -sppPerCall (samples added per render() call), -vpls (traceVPLs before type 4), -png (also write the tonemapped PNG),
+// -filter box|gaussian|mitchell (the film's ImageFilter, Renderer.h:61),
 // -dump file.rtsc (load the scene, write it as a flat file and stop: checks the loaders without a GPU).
 #include <chrono>
 #include <iostream>
@@ -13,7 +14,7 @@ int main(int argc, char* argv[]) {
     std::string sceneName = "cornell-box";
     std::string filename = "radiosity.hdr";   // upstream's default name (Main.cpp:29)
     unsigned int SPP = 8192;
-    int type = 0, width = 1024, height = 1024, perCall = 1, vpls = 0, png = 0;
+    int type = 0, width = 1024, height = 1024, perCall = 1, vpls = 0, png = 0, filter = RT_FILTER_BOX;
     std::string dump;
     unsigned long long seed = 1;
     std::unordered_map<std::string, std::string> args;
@@ -35,6 +36,12 @@ int main(int argc, char* argv[]) {
             else if (pair.first == "-seed") seed = std::stoull(pair.second);
             else if (pair.first == "-sppPerCall") perCall = std::stoi(pair.second);
             else if (pair.first == "-vpls") vpls = std::stoi(pair.second);
+            else if (pair.first == "-filter") {
+                if (pair.second == "box") filter = RT_FILTER_BOX;
+                else if (pair.second == "gaussian") filter = RT_FILTER_GAUSSIAN;
+                else if (pair.second == "mitchell") filter = RT_FILTER_MITCHELL;
+                else throw std::runtime_error("-filter: box, gaussian or mitchell");
+            }
             else if (pair.first == "-png") png = std::stoi(pair.second);
             else if (pair.first == "-dump") dump = pair.second;
             else std::cerr << "Warning: unknown argument '" << pair.first << "'\n";
@@ -55,6 +62,7 @@ int main(int argc, char* argv[]) {
         rt.init(scene);
         rt.type = type;
         rt.seed = seed;
+        if (filter != RT_FILTER_BOX) rt.setFilter(filter);
         if (vpls > 0) rt.traceVPLs(vpls);
         while ((unsigned int)rt.getSPP() < SPP) {
             rt.samplesPerCall = (int)std::min<unsigned int>((unsigned int)perCall, SPP - (unsigned int)rt.getSPP());

@@ -162,6 +162,8 @@ public:
         check(rt_renderer_create(scene->handle, &handle), "RayTracer::init");
     }
     void clear() { check(rt_film_clear(handle), "RayTracer::clear"); }
+    // film->init(w, h, new BoxFilter()) (Renderer.h:61) with another ImageFilter: RT_FILTER_BOX / _GAUSSIAN / _MITCHELL (Imaging.h:138-214)
+    void setFilter(int filter) { check(rt_renderer_set_filter(handle, filter), "RayTracer::setFilter"); }
     void traceVPLs(int N) { check(rt_vpl_trace(handle, N, seed), "RayTracer::traceVPLs"); }   // Renderer.h:772
     void render() {
         if (type == 3) throw std::runtime_error("RayTracer::render: type 3 (OIDN denoise) is outside the hot path");

@@ -15,8 +15,10 @@ s = scenes.interior("bathroom", a.detail, 1920, 1080)
 sc = api.Scene(s, device_build=True)
 
 
-def run(name, mode, spp, vpls=0):
+def run(name, mode, spp, vpls=0, filt=0):
     rt = api.RayTracer(sc)
+    if filt:
+        rt.setFilter(filt)
     if vpls:
         rt.traceVPLs(vpls, 1)
     rt.render(mode, max(1, spp // 4), 1, 0); rt.sync(); rt.clear(); rt.counters(reset=True)
@@ -34,4 +36,7 @@ run("light tracing (type 1)", api.LIGHT, 32)
 run("instant radiosity, 50 VPLs (type 4)", api.RADIOSITY, 2, vpls=50)
 run("instant radiosity, 1024 VPLs", api.RADIOSITY, 1, vpls=1024)
 run("PSSMLT (type 2), 100k proposals/spp", api.MLT, 64)
+run("path tracing, Gaussian film filter", api.PATH, 32, filt=api.FILTER_GAUSSIAN)
+run("path tracing, Mitchell film filter", api.PATH, 32, filt=api.FILTER_MITCHELL)
+run("light tracing, Mitchell film filter", api.LIGHT, 32, filt=api.FILTER_MITCHELL)
 sc.close()
