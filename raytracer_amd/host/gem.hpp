@@ -135,6 +135,14 @@ struct Mesh { PropertyList material; std::vector<StaticVertex> verticesStatic; s
 inline void loadGEM(const std::string& filename, std::vector<Mesh>& meshes) {
     std::ifstream file(filename, std::ios::binary);
     if (!file) throw std::runtime_error("loadScene: cannot open " + filename);
+    file.seekg(0, std::ios::end);
+    const uint64_t fileSize = (uint64_t)file.tellg();
+    file.seekg(0, std::ios::beg);
+    // counts come from the file: check them against what is left of it before sizing anything by them
+    auto need = [&](uint64_t count, uint64_t each) {
+        const uint64_t at = (uint64_t)file.tellg();
+        if (at > fileSize || count > (fileSize - at) / each) throw std::runtime_error("truncated GE model file " + filename);
+    };
     auto u32 = [&]() { uint32_t v = 0; file.read(reinterpret_cast<char*>(&v), 4); if (!file) throw std::runtime_error("truncated GE model file " + filename); return v; };
     auto str = [&]() { uint32_t l = u32(); if (l > (1u << 20)) throw std::runtime_error("bad string length in " + filename); std::string t(l, '\0'); if (l) file.read(&t[0], l); return std::string(t.c_str()); };
     if (u32() != 4058972161u) throw std::runtime_error(filename + " is not a GE Model File");   // upstream: message + exit(0)
@@ -143,14 +151,17 @@ inline void loadGEM(const std::string& filename, std::vector<Mesh>& meshes) {
     for (uint32_t i = 0; i < n; i++) {
         Mesh mesh;
         uint32_t np = u32();
+        need(np, 8);
         for (uint32_t k = 0; k < np; k++) { Property p; p.name = str(); p.value = str(); mesh.material.properties.push_back(p); }
         uint32_t nv = u32();
+        need(nv, isAnimated == 0 ? 44 : 76);
         if (isAnimated == 0) {
             mesh.verticesStatic.resize(nv);
             if (nv) file.read(reinterpret_cast<char*>(mesh.verticesStatic.data()), (std::streamsize)nv * 44);
         } else file.seekg((std::streamoff)nv * 76, std::ios::cur);   // GEMAnimatedVertex (+4 bone ids, 4 weights): loadInstance never reads them
         if (!file) throw std::runtime_error("truncated GE model file " + filename);
         uint32_t ni = u32();
+        need(ni, 4);
         mesh.indices.resize(ni);
         if (ni) file.read(reinterpret_cast<char*>(mesh.indices.data()), (std::streamsize)ni * 4);
         if (!file) throw std::runtime_error("truncated GE model file " + filename);
@@ -270,7 +281,7 @@ inline Image decodePNG(const std::vector<uint8_t>& b, const std::string& name) {
         uint32_t len = be32(o); std::string tag(b.begin() + o + 4, b.begin() + o + 8);
         if (o + 12 + len > b.size()) throw std::runtime_error(name + ": truncated PNG chunk");
         const uint8_t* d = b.data() + o + 8;
-        if (tag == "IHDR") { W = be32(o + 8); H = be32(o + 12); depth = d[8]; ctype = d[9]; interlace = d[12]; }
+        if (tag == "IHDR") { if (len < 13) throw std::runtime_error(name + ": short IHDR"); W = be32(o + 8); H = be32(o + 12); depth = d[8]; ctype = d[9]; interlace = d[12]; }
         else if (tag == "PLTE") plte.assign(d, d + len);
         else if (tag == "IDAT") idat.insert(idat.end(), d, d + len);
         else if (tag == "IEND") break;

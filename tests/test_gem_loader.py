@@ -131,3 +131,21 @@ def test_render_from_gem_directory(tmp_path):
     rt.close(); sc.close()
     # same triangles, materials and samples; the camera matrices differ in the last bits (fp32 MESA inverse vs numpy), so a few paths flip
     assert rel_mse(got, want) < 2e-3 and abs(got.mean() / want.mean() - 1) < 5e-3
+
+
+def test_corrupt_counts_fail_cleanly(tmp_path):
+    """Counts inside a .gem file (meshes, properties, vertices, indices) are checked against the file's size before anything is
+    sized by them: a damaged file is an error message, not a multi-gigabyte allocation."""
+    import struct
+    s = scenes.cornell(32, 32)
+    gem.export_scene(s, str(tmp_path / "scene"))
+    mesh = sorted(p for p in os.listdir(tmp_path / "scene") if p.endswith(".gem"))[0]
+    path = tmp_path / "scene" / mesh
+    good = path.read_bytes()
+    for pos, val in ((8, 0x7FFFFFFF), (12, 0xFFFFFFFF)):    # number of meshes, number of material properties of mesh 0
+        path.write_bytes(good[:pos] + struct.pack("<I", val) + good[pos + 4:])
+        r = subprocess.run([_cli(), "-scene", str(tmp_path / "scene"), "-dump", str(tmp_path / "x.rtsc")], capture_output=True, text=True, timeout=60)
+        assert r.returncode != 0 and "truncated GE model file" in (r.stdout + r.stderr), (pos, r.stdout, r.stderr)
+    path.write_bytes(good[:len(good) // 2])
+    r = subprocess.run([_cli(), "-scene", str(tmp_path / "scene"), "-dump", str(tmp_path / "x.rtsc")], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "truncated" in (r.stdout + r.stderr)
