@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <limits>
 #include <chrono>
+#include <cmath>
 
 namespace {
 
@@ -251,6 +252,11 @@ bool host_scene_build(const rt_scene_desc& d, HostScene& hs, std::string& err, B
     if (d.n_textures && !d.textures) { err = "textures is NULL"; return false; }
     for (uint32_t i = 0; i < d.n_tris; i++)
         if (d.tri_material[i] >= d.n_materials) { err = "tri_material index out of range"; return false; }
+    // a NaN / inf position makes upstream's SAH binning index its 32 bins out of range (Geometry.h:319-383: (int)((centre - min) * scale))
+    for (size_t i = 0; i < (size_t)d.n_tris * 3; i++) {
+        const float* p = d.verts + i * 8;
+        if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) { err = "non-finite vertex position"; return false; }
+    }
     for (uint32_t i = 0; i < d.n_materials; i++) {
         if (d.materials[i].type > RT_MAT_PLASTIC) { err = "unknown material type"; return false; }
         if (d.materials[i].albedo_tex < 0 || (uint32_t)d.materials[i].albedo_tex >= d.n_textures) { err = "albedo_tex out of range"; return false; }
