@@ -217,6 +217,7 @@ extern "C" int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_
 
 extern "C" void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
+    if (s->before_destroy) s->before_destroy(s);
     for (void* p : s->allocs) (void)hipFree(p);
     delete s;
 }
@@ -224,6 +225,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
 extern "C" int rt_scene_set_camera(rt_scene* s, const rt_camera* cam) {
     if (!s || !cam) { rt_set_error("rt_scene_set_camera: NULL argument"); return RT_ERR_INVALID; }
     if (cam->width < 2 || cam->height < 2) { rt_set_error("rt_scene_set_camera: width/height must be >= 2"); return RT_ERR_INVALID; }
+    if (s->before_change) s->before_change(s);   // samples already requested were asked for with the old camera
     host_camera_build(*cam, s->d.cam);
     s->has_camera = true;
     return RT_OK;
@@ -262,6 +264,7 @@ extern "C" int rt_host_build_info(const rt_scene_desc* desc, uint32_t* leaf_orde
 
 extern "C" int rt_counters_enable(rt_scene* s, int enable) {
     if (!s) { rt_set_error("rt_counters_enable: NULL scene"); return RT_ERR_INVALID; }
+    if (s->before_change) s->before_change(s);
     s->count_enabled = enable != 0;
     return RT_OK;
 }

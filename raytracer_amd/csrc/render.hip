@@ -1108,6 +1108,8 @@ struct rt_renderer {
     float* film = nullptr;
     int spp = 0;
     DFilter filter{};   // kind 0 (BoxFilter) until rt_renderer_set_filter
+    // rt_render requests not yet enqueued (see rt_render): consecutive sample ranges of one mode and seed
+    struct Pending { bool active = false; int mode = 0, spp = 0; uint64_t seed = 0, first = 0; } pend;
     uint32_t batch_max = 1;
     uint32_t* spill4 = nullptr;
     uint32_t* spill2 = nullptr;
@@ -1158,8 +1160,21 @@ static int dev_alloc(rt_renderer* r, T** p, size_t count) {
     return RT_OK;
 }
 
+static void flush_scene_renderers(rt_scene* s);
+static int flush_pending(rt_renderer* r);
+// the scene is going away first: finish what its renderers still owe, then cut them loose
+static void orphan_scene_renderers(rt_scene* s) {
+    flush_scene_renderers(s);
+    for (void* q : s->renderers) { rt_renderer* r = static_cast<rt_renderer*>(q); (void)sync_all(r); r->scene = nullptr; }
+    s->renderers.clear();
+}
 extern "C" void rt_renderer_destroy(rt_renderer* r) {
     if (!r) return;
+    r->pend.active = false;   // requested but never looked at
+    if (r->scene) {
+        auto& v = r->scene->renderers;
+        v.erase(std::remove(v.begin(), v.end(), static_cast<void*>(r)), v.end());
+    }
     if (r->stream) { (void)sync_all(r); prof_collect(r); (void)hipStreamDestroy(r->stream); }
     if (r->other.stream) (void)hipStreamDestroy(r->other.stream);
     if (r->acc_event) (void)hipEventDestroy(r->acc_event);
@@ -1213,6 +1228,7 @@ extern "C" int rt_renderer_set_filter(rt_renderer* r, int kind) {
     if (kind != RT_FILTER_BOX && kind != RT_FILTER_GAUSSIAN && kind != RT_FILTER_MITCHELL) {
         rt_set_error("rt_renderer_set_filter: unknown filter"); return RT_ERR_INVALID;
     }
+    { int frc_ = flush_pending(r); if (frc_) return frc_; }   // samples already requested keep the filter they were requested under
     DFilter F{};
     F.kind = kind;
     for (int d = -2; d <= 1; d++) F.g[d + 2] = host_gauss1(d);
@@ -1273,6 +1289,9 @@ extern "C" int rt_renderer_create(rt_scene* scene, rt_renderer** out) {
     if (hipMemsetAsync(r->ctl, 0, sizeof(Ctl), r->stream) != hipSuccess || hipMemsetAsync(r->counters, 0, sizeof(DCounters), r->stream) != hipSuccess ||
         hipMemsetAsync(r->film_own, 0, sizeof(float) * (size_t)r->W * r->H * 3, r->stream) != hipSuccess)
         return fail(RT_ERR_DEVICE);
+    scene->renderers.push_back(r);
+    scene->before_change = flush_scene_renderers;
+    scene->before_destroy = orphan_scene_renderers;
     *out = r;
     return RT_OK;
 }
@@ -1393,16 +1412,16 @@ static int render_mlt(rt_renderer* r, uint32_t chains, uint64_t seed, uint64_t f
     return RT_OK;
 }
 
-extern "C" int rt_render(rt_renderer* r, int mode, int spp, uint64_t seed, uint64_t first_sample) {
-    if (!r || spp < 0) { rt_set_error("rt_render: bad argument"); return RT_ERR_INVALID; }
-    if (mode == RT_MODE_PATH_ST) mode = RT_MODE_PATH;
-    if (mode != RT_MODE_PATH && mode != RT_MODE_LIGHT && mode != RT_MODE_MLT && mode != RT_MODE_RADIOSITY && mode != RT_MODE_AOV_ALBEDO && mode != RT_MODE_AOV_NORMAL &&
-        mode != RT_MODE_DIRECT) { rt_set_error("rt_render: unknown mode"); return RT_ERR_INVALID; }
+static uint32_t batch_limit(const rt_renderer* r, int mode) {
+    if (mode == RT_MODE_LIGHT) return std::max<uint32_t>(1, r->R.cap / ((uint32_t)r->W * r->H));
+    if (mode == RT_MODE_MLT) return std::max<uint32_t>(1, r->R.cap / RT_MLT_PATHS);  // one chain per spp, all chains of a batch side by side
+    return r->batch_max;
+}
+// enqueue `spp` samples now (the film's SPP count is the caller's business)
+static int render_now(rt_renderer* r, int mode, int spp, uint64_t seed, uint64_t first_sample) {
     RT_HIP(hipSetDevice(r->scene->device));
     r->count_enabled = r->scene->count_enabled;  // node/triangle fetch counting (atomics) follows rt_counters_enable
-    uint32_t bmax = r->batch_max;
-    if (mode == RT_MODE_LIGHT) bmax = std::max<uint32_t>(1, r->R.cap / ((uint32_t)r->W * r->H));
-    if (mode == RT_MODE_MLT) bmax = std::max<uint32_t>(1, r->R.cap / RT_MLT_PATHS);  // one chain per spp, all chains of a batch side by side
+    const uint32_t bmax = batch_limit(r, mode);
     int done = 0;
     if ((mode == RT_MODE_PATH || mode == RT_MODE_LIGHT) && spp >= 2 && RT_LANES > 1) {
         // at least two batches, alternating between the two lanes (streams).  Path tracing chains its film accumulation by
@@ -1434,12 +1453,49 @@ extern "C" int rt_render(rt_renderer* r, int mode, int spp, uint64_t seed, uint6
         if (rc) return rc;
         done += (int)b;
     }
+    return RT_OK;
+}
+// Requests held back by rt_render go to the device.  Every entry point that reads or changes what they depend on (film,
+// counters, filter, VPLs, and through rt_scene::before_change the camera) calls this first.
+static int flush_pending(rt_renderer* r) {
+    if (!r->pend.active) return RT_OK;
+    const rt_renderer::Pending p = r->pend;
+    r->pend.active = false;
+    return render_now(r, p.mode, p.spp, p.seed, p.first);
+}
+static void flush_scene_renderers(rt_scene* s) {
+    for (void* q : s->renderers) (void)flush_pending(static_cast<rt_renderer*>(q));
+}
+// Upstream's main loop adds one sample per render() call (Main.cpp:79-137).  One sample per pixel is a 2 M-path launch
+// sequence whose cost is mostly launch tails (16 ms/spp on the bench scene against 5 ms/spp in 16-spp batches), so calls
+// that continue each other -- same mode and seed, first_sample where the last one ended -- are merged and go to the
+// device together once two full batches have gathered, or when anything looks at the result.  Sample indices are
+// explicit, so the film is the one the separate calls would have produced.
+extern "C" int rt_render(rt_renderer* r, int mode, int spp, uint64_t seed, uint64_t first_sample) {
+    if (!r || spp < 0) { rt_set_error("rt_render: bad argument"); return RT_ERR_INVALID; }
+    if (!r->scene) { rt_set_error("rt_render: the renderer's scene has been destroyed"); return RT_ERR_INVALID; }
+    if (mode == RT_MODE_PATH_ST) mode = RT_MODE_PATH;
+    if (mode != RT_MODE_PATH && mode != RT_MODE_LIGHT && mode != RT_MODE_MLT && mode != RT_MODE_RADIOSITY && mode != RT_MODE_AOV_ALBEDO && mode != RT_MODE_AOV_NORMAL &&
+        mode != RT_MODE_DIRECT) { rt_set_error("rt_render: unknown mode"); return RT_ERR_INVALID; }
+    if (spp == 0) return RT_OK;
+    const bool merges = mode == RT_MODE_PATH || mode == RT_MODE_LIGHT || mode == RT_MODE_MLT || mode == RT_MODE_RADIOSITY;
+    const uint32_t full = std::min<uint32_t>(64u, ((mode == RT_MODE_PATH || mode == RT_MODE_LIGHT) ? 2u : 1u) * batch_limit(r, mode));
+    rt_renderer::Pending& p = r->pend;
+    if (p.active && !(merges && p.mode == mode && p.seed == seed && p.first + (uint64_t)p.spp == first_sample)) {
+        int rc = flush_pending(r);
+        if (rc) return rc;
+    }
     r->spp += spp;  // film->incrementSPP() once per render() upstream (Renderer.h:399)
+    if (!merges || (!p.active && (uint32_t)spp >= full)) return render_now(r, mode, spp, seed, first_sample);
+    if (!p.active) { p.active = true; p.mode = mode; p.spp = 0; p.seed = seed; p.first = first_sample; }
+    p.spp += spp;
+    if ((uint32_t)p.spp >= full) return flush_pending(r);
     return RT_OK;
 }
 
 extern "C" int rt_renderer_sync(rt_renderer* r) {
     if (!r) { rt_set_error("rt_renderer_sync: NULL"); return RT_ERR_INVALID; }
+    { int frc_ = flush_pending(r); if (frc_) return frc_; }
     RT_HIP(sync_all(r));
     prof_collect(r);
     return RT_OK;
@@ -1448,6 +1504,7 @@ extern "C" int rt_renderer_sync(rt_renderer* r) {
 // kernel ids: 0 generate, 1 extend, 2 shade, 3 connect, 4 gather, 5 accumulate, 6 control
 extern "C" int rt_profile_enable(rt_renderer* r, int enable) {
     if (!r) { rt_set_error("rt_profile_enable: NULL"); return RT_ERR_INVALID; }
+    { int frc_ = flush_pending(r); if (frc_) return frc_; }
     RT_HIP(sync_all(r));
     prof_collect(r);
     r->profile = enable != 0;
@@ -1455,6 +1512,7 @@ extern "C" int rt_profile_enable(rt_renderer* r, int enable) {
 }
 extern "C" int rt_profile_read(rt_renderer* r, double* ms7, uint32_t* launches7, int reset) {
     if (!r || !ms7 || !launches7) { rt_set_error("rt_profile_read: NULL argument"); return RT_ERR_INVALID; }
+    { int frc_ = flush_pending(r); if (frc_) return frc_; }
     RT_HIP(sync_all(r));
     prof_collect(r);
     for (int i = 0; i < RT_KID_COUNT; i++) { ms7[i] = r->prof_ms[i]; launches7[i] = r->prof_launches[i]; }
@@ -1463,6 +1521,7 @@ extern "C" int rt_profile_read(rt_renderer* r, double* ms7, uint32_t* launches7,
 }
 extern "C" int rt_film_clear(rt_renderer* r) {  // Film::clear (Imaging.h:269)
     if (!r) { rt_set_error("rt_film_clear: NULL"); return RT_ERR_INVALID; }
+    r->pend.active = false;   // samples requested but not yet enqueued would be wiped by this clear anyway
     RT_HIP(hipMemsetAsync(r->film, 0, sizeof(float) * (size_t)r->W * r->H * 3, r->stream));
     r->spp = 0;
     return RT_OK;
@@ -1470,11 +1529,13 @@ extern "C" int rt_film_clear(rt_renderer* r) {  // Film::clear (Imaging.h:269)
 extern "C" int rt_film_spp(const rt_renderer* r) { return r ? r->spp : 0; }
 extern "C" int rt_film_set_spp(rt_renderer* r, int spp) {
     if (!r || spp < 0) { rt_set_error("rt_film_set_spp: bad argument"); return RT_ERR_INVALID; }
+    { int frc_ = flush_pending(r); if (frc_) return frc_; }
     r->spp = spp;
     return RT_OK;
 }
 extern "C" int rt_film_read(rt_renderer* r, float* rgb, int* spp) {
     if (!r || !rgb) { rt_set_error("rt_film_read: NULL argument"); return RT_ERR_INVALID; }
+    { int frc_ = flush_pending(r); if (frc_) return frc_; }
     RT_HIP(sync_all(r));
     RT_HIP(hipMemcpy(rgb, r->film, sizeof(float) * (size_t)r->W * r->H * 3, hipMemcpyDeviceToHost));
     if (spp) *spp = r->spp;
@@ -1482,12 +1543,14 @@ extern "C" int rt_film_read(rt_renderer* r, float* rgb, int* spp) {
 }
 extern "C" int rt_film_bind(rt_renderer* r, float* d_film) {
     if (!r) { rt_set_error("rt_film_bind: NULL"); return RT_ERR_INVALID; }
+    { int frc_ = flush_pending(r); if (frc_) return frc_; }
     RT_HIP(sync_all(r));
     r->film = d_film ? d_film : r->film_own;
     return RT_OK;
 }
 extern "C" int rt_render_counters(rt_renderer* r, rt_counters* o, int reset) {
     if (!r || !o) { rt_set_error("rt_render_counters: NULL argument"); return RT_ERR_INVALID; }
+    { int frc_ = flush_pending(r); if (frc_) return frc_; }
     RT_HIP(sync_all(r));
     Ctl c; DCounters d;
     RT_HIP(hipMemcpy(&c, r->ctl, sizeof(c), hipMemcpyDeviceToHost));
@@ -1510,6 +1573,8 @@ extern "C" int rt_render_counters(rt_renderer* r, rt_counters* o, int reset) {
 extern "C" int rt_vpl_trace(rt_renderer* r, int n_vpls, uint64_t seed) {
     if (!r || n_vpls < 0) { rt_set_error("rt_vpl_trace: bad argument"); return RT_ERR_INVALID; }
     if (n_vpls > (1 << 20)) { rt_set_error("rt_vpl_trace: at most 2^20 light samples"); return RT_ERR_INVALID; }
+    if (!r->scene) { rt_set_error("rt_vpl_trace: the renderer's scene has been destroyed"); return RT_ERR_INVALID; }
+    { int frc_ = flush_pending(r); if (frc_) return frc_; }
     RT_HIP(sync_all(r));
     r->n_vpl = 0; r->R.vpl_slots = 0;
     if (n_vpls == 0) return RT_OK;
@@ -1523,6 +1588,7 @@ extern "C" int rt_vpl_trace(rt_renderer* r, int n_vpls, uint64_t seed) {
     if ((rc = dev_alloc(r, &sp, (size_t)blocks * 64 * std::max<uint32_t>(r->scene->host.max_stack2, 2)))) return rc;
     LAUNCH(k_vpl_trace, blocks, 64, r->scene->d, r->R, n_vpls, seed, sp, r->ctl);
     RT_HIP(hipGetLastError());
+    { int frc_ = flush_pending(r); if (frc_) return frc_; }
     RT_HIP(sync_all(r));
     r->n_vpl = n_vpls; r->R.vpl_slots = (uint32_t)n_vpls * 6;
     return RT_OK;

@@ -36,6 +36,11 @@ struct rt_scene {
     uint32_t* d_spill2 = nullptr;           // stack of the reference-order walk
     int persistent_blocks = 0;
     bool count_enabled = false;
+    // renderers of this scene hold rt_render requests back to merge them (render.hip): whatever changes what those
+    // requests would see (camera, counting) runs this hook first.  Null while no renderer exists.
+    void (*before_change)(rt_scene*) = nullptr;
+    void (*before_destroy)(rt_scene*) = nullptr;   // lets those renderers forget the scene
+    std::vector<void*> renderers;
     std::mutex mu;
 };
 

@@ -92,6 +92,67 @@ def test_batching_and_sample_offsets_compose():
     sc.close()
 
 
+def test_one_sample_per_call_is_merged_and_stays_exact():
+    """Upstream's main loop calls render() once per sample (Main.cpp:79-137).  rt_render merges calls that continue each other
+    and sends them to the device together; what the caller can observe must not change: SPP counts at once, the film equals
+    the single-call film, and anything that changes what a held-back sample would see (camera, filter, clear) takes effect in
+    call order."""
+    from raytracer_amd.abi import Marshalled
+    s = scenes.cornell(96, 96)
+    sc = api.Scene(s)
+    one = api.RayTracer(sc); one.render(api.PATH, 12, 3, 0); want, _ = one.film()
+    a = api.RayTracer(sc)
+    for k in range(12):
+        a.render(api.PATH, 1, 3, k)
+        assert a.getSPP() == k + 1
+    got, n = a.film()
+    assert n == 12 and np.array_equal(got, want)
+    ca, co = a.counters(), one.counters()
+    assert ca["closest_rays"] == co["closest_rays"] and ca["any_rays"] == co["any_rays"]
+    # calls that do not continue each other: each goes out on its own, the film is their sum
+    b = api.RayTracer(sc)
+    for first in (7, 2, 3, 0):
+        b.render(api.PATH, 1, 3, first)
+    parts = []
+    for first, cnt in ((7, 1), (2, 2), (0, 1)):
+        r = api.RayTracer(sc); r.render(api.PATH, cnt, 3, first); parts.append(r.film()[0]); r.close()
+    assert np.allclose(b.film()[0], parts[0] + parts[1] + parts[2], rtol=1e-5, atol=1e-6)
+    # clear() wipes requested samples too; a mode or seed change ends a run
+    b.render(api.PATH, 2, 3, 0); b.clear()
+    assert b.getSPP() == 0 and b.film()[0].max() == 0.0
+    b.render(api.PATH, 1, 3, 0); b.render(api.LIGHT, 1, 3, 1); b.render(api.PATH, 1, 4, 2)
+    r = api.RayTracer(sc); r.render(api.PATH, 1, 3, 0); r.sync(); r.render(api.LIGHT, 1, 3, 1); r.sync(); r.render(api.PATH, 1, 4, 2)
+    fb, fr = b.film()[0], r.film()[0]
+    assert b.getSPP() == 3 and np.allclose(fb, fr, rtol=1e-4, atol=1e-5)   # light-tracer splats are atomics: order only
+    r.close()
+    # a camera change between two calls: sample 0 with the old camera, sample 1 with the new one
+    s2 = scenes.cornell(96, 96)
+    scenes.set_camera(s2, (0.3, 1.1, 3.2), (0.0, 1.0, 0.0), (0, 1, 0), 40.0, 96, 96)
+    cam_old, cam_new = Marshalled(s).cam, Marshalled(s2).cam
+    c = api.RayTracer(sc)
+    c.render(api.PATH, 1, 9, 0)
+    sc.set_camera(cam_new)
+    c.render(api.PATH, 1, 9, 1)
+    got = c.film()[0]
+    d = api.RayTracer(sc); d.render(api.PATH, 1, 9, 1); f_new = d.film()[0]; d.close()
+    sc.set_camera(cam_old)
+    d = api.RayTracer(sc); d.render(api.PATH, 1, 9, 0); f_old = d.film()[0]; d.close()
+    assert not np.allclose(f_new, f_old) and np.allclose(got, f_old + f_new, rtol=1e-5, atol=1e-6)
+    # a filter change likewise
+    e = api.RayTracer(sc)
+    e.render(api.PATH, 1, 9, 0); e.setFilter(api.FILTER_GAUSSIAN); e.render(api.PATH, 1, 9, 1)
+    g = api.RayTracer(sc); g.setFilter(api.FILTER_GAUSSIAN); g.render(api.PATH, 1, 9, 1)
+    assert np.allclose(e.film()[0], f_old + g.film()[0], rtol=1e-5, atol=1e-6)
+    # the scene may go first: its renderers finish what they owe and then refuse new work
+    e.render(api.PATH, 1, 9, 2)
+    sc.close()
+    assert e.getSPP() == 3 and np.isfinite(e.film()[0]).all()
+    with pytest.raises(api.RtError, match="destroyed"):
+        e.render(api.PATH, 1, 9, 3)
+    for r in (one, a, b, c, e, g):
+        r.close()
+
+
 def test_4k_render_sample_partition_composes():
     """BASELINE config 4 shape: bathroom at 3840x2160 (2 spp per batch).  Size-independent properties: two "ranks" with disjoint
     sample ranges sum to the single-renderer film, the film is finite where the frame has no specular fireflies, and
