@@ -1106,6 +1106,7 @@ struct rt_renderer {
     DCounters* counters = nullptr;
     float* film_own = nullptr;
     float* film = nullptr;
+    uint8_t* tonemap_buf = nullptr;   // rt_film_tonemap's device-side image, made on first use
     int spp = 0;
     DFilter filter{};   // kind 0 (BoxFilter) until rt_renderer_set_filter
     // rt_render requests not yet enqueued (see rt_render): consecutive sample ranges of one mode and seed
@@ -1628,15 +1629,26 @@ extern "C" int rt_film_save_hdr(rt_renderer* r, const char* filename) {
     return RT_OK;
 }
 // Film::tonemap (Imaging.h:251)
+// Film::tonemap (Imaging.h:251) for every pixel, on the device: upstream runs it for the whole canvas after every
+// render() (Renderer.h:536-541), so a caller presenting each frame needs it to cost a 6 MB copy, not a 25 MB one plus
+// six million host powf calls.
+__global__ __launch_bounds__(256) void k_tonemap(const float* film, uint8_t* out, size_t n, int spp) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = film[i] * 1.0f / (float)spp;                       // film[...] * exposure / (float)SPP, exposure = 1
+        float m = powf(fmaxf(v, 0.0f), 1.0f / 2.2f) * 255;           // std::max(NaN, 0) is NaN upstream too: the cast below is then unspecified, 0 here
+        out[i] = (uint8_t)(m < 255.0f ? (m > 0.0f ? m : 0.0f) : 255.0f);
+    }
+}
 extern "C" int rt_film_tonemap(rt_renderer* r, uint8_t* rgb8) {
     if (!r || !rgb8) { rt_set_error("rt_film_tonemap: NULL argument"); return RT_ERR_INVALID; }
-    std::vector<float> img((size_t)r->W * r->H * 3);
-    int spp = 0, rc = rt_film_read(r, img.data(), &spp);
-    if (rc) return rc;
-    for (size_t i = 0; i < img.size(); i++) {
-        float v = img[i] * 1.0f / (float)spp;
-        rgb8[i] = (uint8_t)std::min(powf(std::max(v, 0.0f), 1.0f / 2.2f) * 255, 255.0f);
-    }
+    { int frc_ = flush_pending(r); if (frc_) return frc_; }
+    RT_HIP(sync_all(r));
+    const size_t n = (size_t)r->W * r->H * 3;
+    if (!r->tonemap_buf) { int rc = dev_alloc(r, &r->tonemap_buf, n); if (rc) return rc; }
+    LAUNCH(k_tonemap, r->flat_blocks, 256, r->film, r->tonemap_buf, n, r->spp);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipStreamSynchronize(r->stream));
+    RT_HIP(hipMemcpy(rgb8, r->tonemap_buf, n, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

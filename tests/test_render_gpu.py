@@ -153,6 +153,22 @@ def test_one_sample_per_call_is_merged_and_stays_exact():
         r.close()
 
 
+def test_tonemap_on_device_matches_film_tonemap():
+    """Film::tonemap (Imaging.h:251): clamp(pow(max(film / SPP, 0), 1/2.2) * 255) truncated to 8 bits, for the whole frame."""
+    s = scenes.cornell(96, 64, with_specular=True)
+    sc = api.Scene(s); rt = api.RayTracer(sc)
+    rt.render(api.PATH, 6, 2, 0)
+    film, n = rt.film()
+    got = rt.tonemap()
+    v = (film * np.float32(1.0) / np.float32(n)).astype(np.float32)
+    want = np.minimum(np.power(np.maximum(v, np.float32(0)), np.float32(1.0 / 2.2), dtype=np.float32) * np.float32(255), np.float32(255))
+    assert got.shape == (64, 96, 3) and got.dtype == np.uint8
+    d = np.abs(got.astype(np.int32) - np.floor(want).astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3      # powf may differ by an ulp right at an integer boundary
+    assert got.max() == 255 and got.min() == 0
+    rt.close(); sc.close()
+
+
 def test_4k_render_sample_partition_composes():
     """BASELINE config 4 shape: bathroom at 3840x2160 (2 spp per batch).  Size-independent properties: two "ranks" with disjoint
     sample ranges sum to the single-renderer film, the film is finite where the frame has no specular fireflies, and
