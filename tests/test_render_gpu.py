@@ -223,6 +223,36 @@ def test_full_size_light_tracing_same_seed():
     assert close.mean() > 0.9995 and abs(a.sum() / b.sum() - 1) < 1e-3
 
 
+def test_full_size_radiosity_and_pssmlt_same_seed():
+    """BASELINE config 5 shape on the bathroom-class 1080p frame: instant radiosity (2 light samples -> 5 VPLs) and one PSSMLT
+    chain, same numbers on both sides.  The radiosity film also carries the rough dielectric's NaN pixels: same pixels."""
+    s = scenes.bathroom(1.0, 1920, 1080)
+    o = orc.OracleScene(s)
+    sc = api.Scene(s, device_build=True)
+    n = o.vpl_trace(2, seed=9)
+    want, st = o.render(4, 1, seed=9, threads=16)
+    rt = api.RayTracer(sc)
+    assert rt.traceVPLs(2, 9) == n
+    rt.render(api.RADIOSITY, 1, 9, 0); got, _ = rt.film(); cnt = rt.counters()
+    fw, fg = np.isfinite(want).all(axis=2), np.isfinite(got).all(axis=2)
+    assert (fw ^ fg).sum() <= 1 and abs(cnt["closest_rays"] / st["closest_rays"] - 1) < 1e-4
+    both = fw & fg
+    a, b = got[both].astype(np.float64), want[both].astype(np.float64)
+    close = (np.abs(a - b) <= 1e-3 * np.maximum(np.abs(a), np.abs(b)) + 1e-4).all(axis=1)
+    assert close.mean() > 0.999
+    # the GPU only shoots the (point, VPL) pairs that face each other; upstream tests visibility first (Renderer.h:883)
+    assert cnt["any_rays"] <= st["any_rays"]
+    rt.clear()
+    want = o.mlt_render(1, seed=11)
+    rt.render(api.MLT, 1, 11, 0); got, _ = rt.film()
+    f = lambda a: np.nan_to_num(a, nan=0.0, posinf=0.0, neginf=0.0).astype(np.float64).reshape(135, 8, 240, 8, 3).sum((1, 3))
+    assert np.array_equal(np.isfinite(got), np.isfinite(want)) or (np.isfinite(got) ^ np.isfinite(want)).sum() <= 6
+    gw, gg = f(want), f(got)
+    ok = (np.abs(gw) < 1e3) & (np.abs(gg) < 1e3)                       # fireflies aside
+    assert ok.mean() > 0.99 and np.abs(gg[ok] - gw[ok]).sum() <= 2e-2 * np.abs(gw[ok]).sum()
+    rt.close(); sc.close()
+
+
 @pytest.mark.parametrize("mode", [api.AOV_ALBEDO, api.AOV_NORMAL, api.DIRECT])
 def test_aov_and_direct_passes(mode):
     s = scenes.interior("bathroom", 0.1, 160, 90)
