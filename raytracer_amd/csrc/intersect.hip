@@ -29,19 +29,26 @@ extern "C" int rt_device_set(int device) {
 }
 
 // ------------------------------------------------------------------------------------------------ kernels
-// Work source of the batch kernels: one counter, RT_GRANT consecutive items per atomic.
-#define RT_GRANT 256u
+// Work source of the batch kernels: one counter, `grant` consecutive items per atomic -- 256 for big batches (one
+// contended atomic costs ~11 ns), fewer when the batch is small enough that a wave's last grant would be a large part of
+// the launch (about 16 grants per wave, at least 64 items).
 struct CounterSource {
     unsigned long long* work;
-    uint32_t n;
+    uint32_t n, grant;
+    __device__ __forceinline__ void init(unsigned long long* w, uint32_t count) {
+        work = w; n = count;
+        const uint32_t want = count / (gridDim.x * (blockDim.x >> 6) * 16u);
+        grant = 256u;
+        while (grant > 64u && grant > want) grant >>= 1;
+    }
     __device__ __forceinline__ bool next(uint32_t& begin, uint32_t& end) {
         unsigned long long base = 0;
-        if ((threadIdx.x & 63) == 0) base = atomicAdd(work, (unsigned long long)RT_GRANT);
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(work, (unsigned long long)grant);
         unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
         unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
         if (hi != 0 || lo >= n) return false;
         begin = lo;
-        end = (n - lo) < RT_GRANT ? n : lo + RT_GRANT;
+        end = (n - lo) < grant ? n : lo + grant;
         return true;
     }
 };
@@ -89,7 +96,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_intersect_closest(D
     RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
     uint32_t cn = 0, ct = 0, cx = 0;
     ClosestJob job{S, rays, out, 0u};
-    CounterSource src{work, n};
+    CounterSource src; src.init(work, n);
     rt_persistent_walk<false, COUNT>(S, job, src, mode, st, spill2 + gtid, gstride, cn, ct, cx, counters);
     if (COUNT) {
         atomicAdd(&counters->closest, (unsigned long long)job.done); atomicAdd(&counters->nodes, (unsigned long long)cn);
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_intersect_any(DScen
     RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
     uint32_t cn = 0, ct = 0, cx = 0;
     AnyJob job{segs, out, 0u};
-    CounterSource src{work, n};
+    CounterSource src; src.init(work, n);
     rt_persistent_walk<true, COUNT>(S, job, src, mode, st, spill2 + gtid, gstride, cn, ct, cx, counters);
     if (COUNT) {
         atomicAdd(&counters->any, (unsigned long long)job.done); atomicAdd(&counters->any_nodes, (unsigned long long)cn);

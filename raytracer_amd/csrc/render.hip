@@ -55,9 +55,17 @@ __device__ __forceinline__ unsigned long long fetch_chunk(unsigned long long* wo
     unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
     return ((unsigned long long)hi << 32) | lo;
 }
-// A wave takes RT_FETCH_CHUNKS x 64 consecutive items per atomic: one contended device-scope atomic costs ~11 ns
-// (MI355X_MICROARCH.md "fanin"/"dequeue"), so per-64-item fetches alone would cap a kernel at ~5.8 G items/s.
-#define RT_FETCH_CHUNKS 4
+// A wave takes `grant` consecutive items per atomic.  One contended device-scope atomic costs ~11 ns (MI355X_MICROARCH.md
+// "fanin"/"dequeue"), so 64-item grants alone would cap a kernel at ~5.8 G items/s: big launches take 256.  A launch ends
+// with its last grants, though, and a 256-item grant is ~0.5 ms of work for one wave: with 2 M items (one sample per pixel)
+// that is a third of the launch spent waiting for the waves that drew a second grant.  So the grant shrinks with the
+// launch: about RT_GRANTS_PER_WAVE grants per wave, between RT_GRANT_MIN and 256 items.
+#ifndef RT_GRANTS_PER_WAVE
+#define RT_GRANTS_PER_WAVE 16u
+#endif
+#ifndef RT_GRANT_MIN
+#define RT_GRANT_MIN 64u
+#endif
 #ifndef RT_XCD_SHARD
 #define RT_XCD_SHARD 1
 #endif
@@ -66,14 +74,17 @@ __device__ __forceinline__ unsigned long long fetch_chunk(unsigned long long* wo
 // compaction, so a shard is a spatially coherent part of the frame and its BVH working set stays in that XCD's 4 MB
 // L2 instead of being replicated in all eight.  Placement only affects speed, never results.
 struct XcdFetch {
-    uint32_t xcc, step, per;
+    uint32_t xcc, step, per, grant;
     __device__ __forceinline__ void init(uint32_t n) {
         xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;  // HW_REG_XCC_ID[3:0]
         step = 0;
-        uint32_t unit = 64u * RT_FETCH_CHUNKS;
-        per = (((n + 7u) / 8u + unit - 1u) / unit) * unit;
+        const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+        const uint32_t want = n / (waves * RT_GRANTS_PER_WAVE);
+        grant = 256u;
+        while (grant > RT_GRANT_MIN && grant > want) grant >>= 1;
+        per = (((n + 7u) / 8u + grant - 1u) / grant) * grant;
     }
-    // returns false when every shard is exhausted; otherwise [base, end) with base a multiple of 64
+    // returns false when every shard is exhausted; otherwise [base, end) with base a multiple of the grant
     __device__ __forceinline__ bool next(unsigned long long (*w)[16], uint32_t n, uint32_t& base, uint32_t& end) {
         while (step < 8) {
             uint32_t sh = RT_XCD_SHARD ? ((xcc + step) & 7u) : step;
@@ -81,7 +92,7 @@ struct XcdFetch {
             if (hi > n) hi = n;
             if (lo < hi) {
                 unsigned long long b = 0;
-                if ((threadIdx.x & 63) == 0) b = atomicAdd(&w[sh][0], 64ULL * RT_FETCH_CHUNKS);
+                if ((threadIdx.x & 63) == 0) b = atomicAdd(&w[sh][0], (unsigned long long)grant);
                 uint32_t b32 = __builtin_amdgcn_readfirstlane((unsigned)b);
                 if (lo + b32 < hi) { base = (uint32_t)lo + b32; end = (uint32_t)hi; return true; }
             }
@@ -221,7 +232,7 @@ struct XcdSource {   // rt_persistent_walk's Source over the XCD-sharded work co
         uint32_t b, e;
         if (!xf.next(w, n, b, e)) return false;
         begin = b;
-        end = (e - b) < 64u * RT_FETCH_CHUNKS ? e : b + 64u * RT_FETCH_CHUNKS;
+        end = (e - b) < xf.grant ? e : b + xf.grant;
         return true;
     }
 };

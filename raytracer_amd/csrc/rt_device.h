@@ -498,7 +498,7 @@ __device__ __forceinline__ bool rt_visible_begin(const DScene& S, f3 p1, f3 p2, 
 // ---- persistent traversal with lane refill (Aila & Laine's "persistent while-while" idea at wave64 width).
 // With one ray per lane per 64-ray chunk a wave runs until its slowest ray is done; PMC counters put the average
 // number of live lanes per VALU instruction at ~11 of 64 that way.  Here a wave keeps a private pool of item
-// indices (one work atomic per RT_FETCH_CHUNKS*64 items); whenever at least RT_REFILL_IDLE lanes are idle the finished
+// indices (one work atomic per grant of 64-256 items); whenever at least RT_REFILL_IDLE lanes are idle the finished
 // lanes retire their result together and every idle lane is handed the next item of the pool.
 //   Job:    bool load(uint32_t item, f3& a, f3& b)   -- closest: origin, direction; any: p1, p2.  false = nothing to trace
 //           void retire(uint32_t item, const Walk& w, bool visible)
@@ -507,6 +507,21 @@ __device__ __forceinline__ bool rt_visible_begin(const DScene& S, f3 p1, f3 p2, 
 #ifndef RT_REFILL_IDLE
 #define RT_REFILL_IDLE 16
 #endif
+
+// Tail: once the source is drained a wave is left with its slowest walks -- a few rays that take 1000+ steps where the mean
+// is 50 -- and the launch lasts until they end.  From then on idle lanes take work from busy ones: every RT_STEAL_EVERY steps
+// a lane that holds a walk hands the top entry of its stack (the subtree it would enter next) to a free lane, which gets a
+// copy of the ray and the best hit so far and walks that subtree on its own.  The parts of one item are folded together when
+// the wave is done: closest hit = the minimum by (t, rank), the order the single walk applies; any hit = OR.  A part can only
+// miss hits that its copy of best.t already beats, so the result is the single walk's, bit for bit.
+#ifndef RT_TAIL_STEAL
+#define RT_TAIL_STEAL 1
+#endif
+#ifndef RT_STEAL_EVERY
+#define RT_STEAL_EVERY 4
+#endif
+__device__ __forceinline__ float rt_shfl_f(float v, uint32_t src) { return __shfl(v, (int)src); }
+__device__ __forceinline__ f3 rt_shfl_f3(f3 v, uint32_t src) { return mk3(__shfl(v.x, (int)src), __shfl(v.y, (int)src), __shfl(v.z, (int)src)); }
 
 template <bool ANY, bool COUNT, class Job, class Source>
 __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, Source& src, int mode, TravStack& st, uint32_t* spill2,
@@ -525,7 +540,7 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
             if (done) { job.retire(item, w, visible); done = false; }
             if (drained) break;
             if (pb >= pe) {
-                if (!src.next(pb, pe)) { drained = true; continue; }
+                if (!src.next(pb, pe)) { drained = true; if (RT_TAIL_STEAL) break; continue; }
             }
             uint32_t take = pe - pb;
             take = take < nidle ? take : nidle;
@@ -547,6 +562,76 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
         if (rt_vote_step<ANY, COUNT>(S, w, busy, st, cn, ct)) {
             busy = false; done = true;
             if (ANY) visible = !w.occluded;
+        }
+    }
+    if (RT_TAIL_STEAL) {
+        // every lane is busy (walking) or free here: finished lanes retired above
+        unsigned long long split = 0;   // lanes whose result is one part of an item (wave-uniform)
+        for (uint32_t round = 0;; round++) {
+            const unsigned long long bm = __ballot(busy);
+            if (!bm) break;
+            if ((round % (uint32_t)RT_STEAL_EVERY) == 0u) {
+                const unsigned long long fm = __ballot(!busy && !done);      // free: no walk, no result to keep
+                const unsigned long long dm = __ballot(busy && w.sp >= 1u);  // donors: a subtree waiting on the stack
+                uint32_t n = (uint32_t)__popcll(fm), nd = (uint32_t)__popcll(dm);
+                n = n < nd ? n : nd;
+                if (n) {
+                    const uint32_t lt_f = (uint32_t)__popcll(fm & ((1ULL << lane) - 1ULL)), lt_d = (uint32_t)__popcll(dm & ((1ULL << lane) - 1ULL));
+                    const bool thief = ((fm >> lane) & 1ULL) && lt_f < n, donor = ((dm >> lane) & 1ULL) && lt_d < n;
+                    uint32_t from = lane;   // a thief's donor: the lt_f-th set bit of dm
+                    unsigned long long bits = dm;
+                    for (uint32_t j = 0; j < n; j++) {
+                        const uint32_t l = (uint32_t)__ffsll((long long)bits) - 1u;
+                        if (thief && lt_f == j) from = l;
+                        bits &= bits - 1ULL;
+                    }
+                    uint32_t give = 0;
+                    if (donor) { float key; give = st.get(--w.sp, key); }
+                    // the ray and what is known about it so far travel by shuffle; non-thieves read themselves
+                    const f3 o_ = rt_shfl_f3(w.o, from), d_ = rt_shfl_f3(w.dir, from), i_ = rt_shfl_f3(w.inv, from), p_ = rt_shfl_f3(w.pad, from);
+                    const float mt_ = rt_shfl_f(w.maxT, from), pt_ = rt_shfl_f(w.padt, from);
+                    const float bt_ = rt_shfl_f(w.best.t, from), bu_ = rt_shfl_f(w.best.u, from), bv_ = rt_shfl_f(w.best.v, from);
+                    const uint32_t br_ = (uint32_t)__shfl((int)w.best.rank, (int)from);
+                    const uint32_t sx_ = (uint32_t)__shfl((int)w.sx, (int)from), sy_ = (uint32_t)__shfl((int)w.sy, (int)from), sz_ = (uint32_t)__shfl((int)w.sz, (int)from);
+                    const uint32_t it_ = (uint32_t)__shfl((int)item, (int)from), cur_ = (uint32_t)__shfl((int)give, (int)from);
+                    if (thief) {
+                        w.o = o_; w.dir = d_; w.inv = i_; w.pad = p_; w.maxT = mt_; w.padt = pt_;
+                        w.best.t = bt_; w.best.u = bu_; w.best.v = bv_; w.best.rank = br_;
+                        w.sx = sx_; w.sy = sy_; w.sz = sz_; w.cur = cur_; w.sp = 0; w.occluded = false;
+                        item = it_; busy = true; visible = true;
+                        if (COUNT) c_mine = 0;
+                    }
+                    split |= __ballot(thief || donor);
+                }
+            }
+            if (COUNT) { c_slots++; c_busy += busy ? 1u : 0u; c_mine += busy ? 1u : 0u; c_max = c_mine > c_max ? c_mine : c_max; }
+            if (rt_vote_step<ANY, COUNT>(S, w, busy, st, cn, ct)) {
+                busy = false; done = true;
+                if (ANY) visible = !w.occluded;
+            }
+        }
+        // results that were never part of a split retire together
+        if (done && !((split >> lane) & 1ULL)) { job.retire(item, w, visible); done = false; }
+        unsigned long long hm = __ballot(done);
+        while (hm) {
+            const uint32_t leader = (uint32_t)__ffsll((long long)hm) - 1u;
+            const uint32_t it = (uint32_t)__shfl((int)item, (int)leader);
+            const unsigned long long same = __ballot(done && item == it);
+            if (ANY) {
+                const bool vis = __ballot(done && item == it && !visible) == 0ULL;
+                if (lane == leader) visible = vis;
+            } else {
+                unsigned long long rest = same & ~(1ULL << leader);
+                while (rest) {
+                    const uint32_t l = (uint32_t)__ffsll((long long)rest) - 1u;
+                    const float t2 = rt_shfl_f(w.best.t, l), u2 = rt_shfl_f(w.best.u, l), v2 = rt_shfl_f(w.best.v, l);
+                    const uint32_t r2 = (uint32_t)__shfl((int)w.best.rank, (int)l);
+                    if (lane == leader && (t2 < w.best.t || (t2 == w.best.t && r2 < w.best.rank))) { w.best.t = t2; w.best.u = u2; w.best.v = v2; w.best.rank = r2; }
+                    rest &= rest - 1ULL;
+                }
+            }
+            if (lane == leader) job.retire(item, w, visible);
+            hm &= ~same;
         }
     }
     if (COUNT) {
