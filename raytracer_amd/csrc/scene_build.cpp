@@ -21,6 +21,8 @@
 #include <algorithm>
 #include <limits>
 #include <chrono>
+#include <thread>
+#include <atomic>
 #include <cmath>
 
 namespace {
@@ -161,10 +163,12 @@ struct Builder {
 // ---- 4-wide collapse -------------------------------------------------------------------------------------------
 struct Slot { Aabb box; int bnode; /* >= 0: inner reference node to expand */ uint32_t first, count; /* leaf range */ };
 
+struct CollapseJob { int bnode; uint32_t parent; int slot; std::vector<DNode4> nodes; };
 struct Collapser {
     const std::vector<BNode>& bn;
     std::vector<DNode4>& out;
-    uint32_t max_stack = 0;
+    uint32_t cutoff = 0;                       // > 0: subtrees of at most this many triangles are left to `jobs`
+    std::vector<CollapseJob>* jobs = nullptr;
 
     bool single(int i) const { return bn[i].left < 0 && bn[i].count <= 1; }
     bool is_leaf(int i) const { return bn[i].left < 0; }
@@ -229,7 +233,10 @@ struct Collapser {
         uint32_t worst = 0;
         for (size_t k = 0; k < slots.size(); k++) {
             uint32_t nd = 0, ref;
-            if (slots[k].bnode >= 0) ref = emit(slots[k].bnode, nd);
+            if (slots[k].bnode >= 0 && cutoff && bn[slots[k].bnode].count <= cutoff) {
+                jobs->push_back(CollapseJob{ slots[k].bnode, ni, (int)k, {} });   // collapsed on another thread, spliced in later
+                ref = RT_REF_EMPTY;
+            } else if (slots[k].bnode >= 0) ref = emit(slots[k].bnode, nd);
             else ref = emit_leaf(slots[k].box, slots[k].first, slots[k].count, nd);
             set_child(out[ni], (int)k, slots[k].box, ref);
             worst = std::max(worst, nd);
@@ -238,6 +245,18 @@ struct Collapser {
         return ni;
     }
 };
+
+// Entries a walk can have waiting below wide node `i`: its other children, plus the worst of what a child needs.
+static uint32_t wide_stack_need(const std::vector<DNode4>& n, uint32_t i) {
+    uint32_t used = 0, worst = 0;
+    for (int k = 0; k < 4; k++) {
+        const uint32_t ref = n[i].child[k];
+        if (ref == RT_REF_EMPTY) continue;
+        used++;
+        if (!(ref & RT_REF_LEAF)) worst = std::max(worst, wide_stack_need(n, ref));
+    }
+    return (used ? used - 1 : 0) + worst;
+}
 
 inline void put3(float* d, F3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
 inline float lum(const float* c) { return ((0.2126f * c[0]) + (0.7152f * c[1]) + (0.0722f * c[2])); }  // Colour::Lum (Core.h:89)
@@ -313,67 +332,119 @@ bool host_scene_build(const rt_scene_desc& d, HostScene& hs, std::string& err, B
     hs.depth2 = b.max_depth; hs.leaves2 = b.leaves; hs.max_leaf2 = b.max_leaf;
     hs.max_stack2 = b.max_depth + 2;
 
-    // triangle records in DFS order + scene bounds (Scene::init, Scene.h:152-158)
+    // triangle records in DFS order + scene bounds (Scene::init, Scene.h:152-158), the reference-topology nodes and the
+    // 4-wide collapse only read the binary tree: the three run side by side, the records on several threads (the partial
+    // bounds are folded in order below)
     Aabb bounds;
     hs.tris.resize(d.n_tris); hs.trishade.resize(d.n_tris);
     std::vector<uint32_t> rank_of(d.n_tris);
     float amax = 0;
-    for (uint32_t r = 0; r < d.n_tris; r++) {
-        uint32_t t = b.order[r];
-        rank_of[t] = r;
-        const float* f = d.verts + (size_t)t * 24;
-        F3 p0 = f3(f[0], f[1], f[2]), p1 = f3(f[8], f[9], f[10]), p2 = f3(f[16], f[17], f[18]);
-        F3 e1 = sub(p2, p1), e2 = sub(p0, p2);
-        F3 n = normalize(cross(e1, e2));
-        DTri& o = hs.tris[r];
-        put3(o.v0, p0); put3(o.v1, p1); put3(o.v2, p2); put3(o.n, n);
-        o.d = dot(n, p0);
-        o.inv_area = 1.0f / dot(cross(e1, e2), n);
-        o.orig_id = t;
-        F3 n0 = f3(f[3], f[4], f[5]);
-        bool flip = !(dot(n0, n) > 0);  // gNormal = n * (Dot(v0.normal, n) > 0 ? 1 : -1)
-        o.mat_gsign = d.tri_material[t] | (flip ? 0x80000000u : 0u);
-        DTriShade& s = hs.trishade[r];
-        put3(s.n0, n0); put3(s.n1, f3(f[11], f[12], f[13])); put3(s.n2, f3(f[19], f[20], f[21]));
-        s.uv[0] = f[6]; s.uv[1] = f[7]; s.uv[2] = f[14]; s.uv[3] = f[15]; s.uv[4] = f[22]; s.uv[5] = f[23];
-        s.area = length(cross(e1, e2)) * 0.5f;
-        bounds.grow(p0); bounds.grow(p1); bounds.grow(p2);
-        for (int k = 0; k < 3; k++) for (int c = 0; c < 3; c++) amax = std::max(amax, fabsf(f[k * 8 + c]));
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const uint32_t nthr = (uint32_t)std::min<uint64_t>(std::min(16u, hw), std::max<uint64_t>(1, d.n_tris / 65536));
+    std::vector<Aabb> part_bounds(nthr);
+    std::vector<float> part_amax(nthr, 0.0f);
+    auto records = [&](uint32_t ti) {
+        const uint32_t r0 = (uint32_t)((uint64_t)d.n_tris * ti / nthr), r1 = (uint32_t)((uint64_t)d.n_tris * (ti + 1) / nthr);
+        Aabb bounds; float amax = 0;
+        for (uint32_t r = r0; r < r1; r++) {
+            uint32_t t = b.order[r];
+            rank_of[t] = r;
+            const float* f = d.verts + (size_t)t * 24;
+            F3 p0 = f3(f[0], f[1], f[2]), p1 = f3(f[8], f[9], f[10]), p2 = f3(f[16], f[17], f[18]);
+            F3 e1 = sub(p2, p1), e2 = sub(p0, p2);
+            F3 n = normalize(cross(e1, e2));
+            DTri& o = hs.tris[r];
+            put3(o.v0, p0); put3(o.v1, p1); put3(o.v2, p2); put3(o.n, n);
+            o.d = dot(n, p0);
+            o.inv_area = 1.0f / dot(cross(e1, e2), n);
+            o.orig_id = t;
+            F3 n0 = f3(f[3], f[4], f[5]);
+            bool flip = !(dot(n0, n) > 0);  // gNormal = n * (Dot(v0.normal, n) > 0 ? 1 : -1)
+            o.mat_gsign = d.tri_material[t] | (flip ? 0x80000000u : 0u);
+            DTriShade& s = hs.trishade[r];
+            put3(s.n0, n0); put3(s.n1, f3(f[11], f[12], f[13])); put3(s.n2, f3(f[19], f[20], f[21]));
+            s.uv[0] = f[6]; s.uv[1] = f[7]; s.uv[2] = f[14]; s.uv[3] = f[15]; s.uv[4] = f[22]; s.uv[5] = f[23];
+            s.area = length(cross(e1, e2)) * 0.5f;
+            bounds.grow(p0); bounds.grow(p1); bounds.grow(p2);
+            for (int k = 0; k < 3; k++) for (int c = 0; c < 3; c++) amax = std::max(amax, fabsf(f[k * 8 + c]));
+        }
+        part_bounds[ti] = bounds; part_amax[ti] = amax;
+    };
+    std::vector<std::thread> workers;
+    for (uint32_t ti = 1; ti < nthr; ti++) workers.emplace_back(records, ti);
+    std::thread tree([&]() {
+        // reference-topology device nodes
+        hs.nodes2.resize(b.nodes.size());
+        for (size_t i = 0; i < b.nodes.size(); i++) {
+            const BNode& s = b.nodes[i];
+            DNode2& o = hs.nodes2[i];
+            put3(o.lo, s.box.lo); put3(o.hi, s.box.hi);
+            o.left = s.left; o.right = s.right; o.first = (int32_t)s.first; o.count = (int32_t)s.nleaf; o.pad0 = o.pad1 = 0;
+        }
+        // 4-wide tree
+        if (d.n_tris > 0) {
+            Collapser col{ b.nodes, hs.nodes4 };
+            const BNode& root = b.nodes[0];
+            uint32_t need = 0;
+            if (root.left < 0 || (col.single(root.left) && col.single(root.right))) {
+                // the whole scene is one leaf slot; a single-triangle root has no real box anywhere above it
+                Aabb box = root.count >= 2 ? root.box : Aabb();
+                if (root.count < 2) { box.lo = f3(-Aabb::FLT_MAX_, -Aabb::FLT_MAX_, -Aabb::FLT_MAX_); box.hi = f3(Aabb::FLT_MAX_, Aabb::FLT_MAX_, Aabb::FLT_MAX_); }
+                hs.nodes4.push_back(Collapser::empty_node());
+                uint32_t nd = 0;
+                uint32_t ref = col.emit_leaf(box, 0, d.n_tris, nd);
+                Collapser::set_child(hs.nodes4[0], 0, box, ref);
+                need = nd;
+            } else {
+                // the top of the tree here, subtrees of <= n/64 triangles on worker threads into vectors of their own, then
+                // spliced behind it (inner references shifted by where each vector lands); same nodes, another numbering
+                std::vector<CollapseJob> jobs;
+                col.cutoff = d.n_tris >= (1u << 16) ? std::max<uint32_t>(1024u, d.n_tris / 64u) : 0u;
+                col.jobs = &jobs;
+                col.emit(0, need);
+                std::atomic<size_t> next{0};
+                auto work = [&]() {
+                    for (size_t j; (j = next.fetch_add(1)) < jobs.size();) {
+                        Collapser sub{ b.nodes, jobs[j].nodes };
+                        uint32_t nd = 0;
+                        sub.emit(jobs[j].bnode, nd);
+                    }
+                };
+                std::vector<std::thread> pool;
+                for (uint32_t ti = 1; ti < std::min<uint32_t>(nthr, (uint32_t)jobs.size()); ti++) pool.emplace_back(work);
+                work();
+                for (auto& t : pool) t.join();
+                for (CollapseJob& j : jobs) {
+                    const uint32_t base = (uint32_t)hs.nodes4.size();
+                    for (DNode4& n : j.nodes)
+                        for (int k = 0; k < 4; k++)
+                            if (n.child[k] != RT_REF_EMPTY && !(n.child[k] & RT_REF_LEAF)) n.child[k] += base;
+                    hs.nodes4.insert(hs.nodes4.end(), j.nodes.begin(), j.nodes.end());
+                    hs.nodes4[j.parent].child[j.slot] = base;
+                    std::vector<DNode4>().swap(j.nodes);
+                }
+                need = wide_stack_need(hs.nodes4, 0);
+            }
+            hs.max_stack4 = need + 2;
+        }
+        if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "  nodes2 + collapse thread done at %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    });
+    records(0);
+    for (auto& t : workers) t.join();
+    if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "  records (%u threads) done at %.3f s\n", nthr, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    tree.join();
+    if (hs.nodes4.size() > (1u << 25)) { err = "wide BVH exceeds 2^25 nodes (32-bit node offsets)"; return false; }
+    for (uint32_t ti = 0; ti < nthr; ti++) {
+        const Aabb& q = part_bounds[ti];   // folded in order with extend's own ternaries: the same bits as one pass, signed zeros included
+        bounds.hi = f3(bounds.hi.x > q.hi.x ? bounds.hi.x : q.hi.x, bounds.hi.y > q.hi.y ? bounds.hi.y : q.hi.y, bounds.hi.z > q.hi.z ? bounds.hi.z : q.hi.z);
+        bounds.lo = f3(bounds.lo.x < q.lo.x ? bounds.lo.x : q.lo.x, bounds.lo.y < q.lo.y ? bounds.lo.y : q.lo.y, bounds.lo.z < q.lo.z ? bounds.lo.z : q.lo.z);
+        amax = std::max(amax, part_amax[ti]);
     }
     hs.abs_max = amax;
     put3(hs.bounds_lo, bounds.lo); put3(hs.bounds_hi, bounds.hi);
     F3 c = f3((bounds.hi.x + bounds.lo.x) * 0.5f, (bounds.hi.y + bounds.lo.y) * 0.5f, (bounds.hi.z + bounds.lo.z) * 0.5f);
     put3(hs.centre, c);
     hs.radius = length(sub(bounds.hi, c));
-
-    // reference-topology device nodes
-    hs.nodes2.resize(b.nodes.size());
-    for (size_t i = 0; i < b.nodes.size(); i++) {
-        const BNode& s = b.nodes[i];
-        DNode2& o = hs.nodes2[i];
-        put3(o.lo, s.box.lo); put3(o.hi, s.box.hi);
-        o.left = s.left; o.right = s.right; o.first = (int32_t)s.first; o.count = (int32_t)s.nleaf; o.pad0 = o.pad1 = 0;
-    }
-    // 4-wide tree
-    if (d.n_tris > 0) {
-        Collapser col{ b.nodes, hs.nodes4 };
-        const BNode& root = b.nodes[0];
-        uint32_t need = 0;
-        if (root.left < 0 || (col.single(root.left) && col.single(root.right))) {
-            // the whole scene is one leaf slot; a single-triangle root has no real box anywhere above it
-            Aabb box = root.count >= 2 ? root.box : Aabb();
-            if (root.count < 2) { box.lo = f3(-Aabb::FLT_MAX_, -Aabb::FLT_MAX_, -Aabb::FLT_MAX_); box.hi = f3(Aabb::FLT_MAX_, Aabb::FLT_MAX_, Aabb::FLT_MAX_); }
-            hs.nodes4.push_back(Collapser::empty_node());
-            uint32_t nd = 0;
-            uint32_t ref = col.emit_leaf(box, 0, d.n_tris, nd);
-            Collapser::set_child(hs.nodes4[0], 0, box, ref);
-            need = nd;
-        } else {
-            col.emit(0, need);
-        }
-        hs.max_stack4 = need + 2;
-        if (hs.nodes4.size() > (1u << 25)) { err = "wide BVH exceeds 2^25 nodes (32-bit node offsets)"; return false; }
-    }
 
     if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "records + collapse done at %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     // light list: background first if it has power (Scene.h:164), then emissive triangles in caller order (Scene.h:107)
