@@ -107,13 +107,14 @@ int rt_device_count(void);
 int rt_device_set(int device);
 
 /* --- Scene::init + Scene::build (Scene.h:150, :92): Triangle::init precompute, reference-topology
- * binned-SAH BVH (Geometry.h:310-438), light list (Scene.h:107-116), flatten + upload. */
+ * binned-SAH BVH (Geometry.h:310-438), light list (Scene.h:107-116), flatten + upload.
+ * The binned-SAH build of the binary tree (BVHNode::build, Geometry.h:391-438 -- 85 % of scene set-up time when it
+ * runs on the host) runs on the GPU, level by level; the tree, the leaf order and every traversal result are the
+ * same as with the host build (tests/test_bvh_build_gpu.py), which rt_scene_create_ex can still ask for. */
 int rt_scene_create(const rt_scene_desc* desc, rt_scene** out);
-/* The same with build options.  RT_SCENE_BUILD_DEVICE: the binned-SAH build of the binary tree (BVHNode::build,
- * Geometry.h:391-438 -- 85 % of scene set-up time on the host) runs on the GPU, level by level; the tree, the leaf
- * order and every traversal result are the same as with the host build (tests/test_bvh_build_gpu.py). */
-#define RT_SCENE_BUILD_DEVICE 1u
-int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_scene** out);
+#define RT_SCENE_BUILD_DEVICE 1u   /* the default of rt_scene_create */
+#define RT_SCENE_BUILD_HOST 2u     /* single-threaded host build of the binary tree */
+int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_scene** out);   /* flags: one of the two, or 0 = default */
 void rt_scene_destroy(rt_scene* scene);
 /* --- Camera::init + Camera::updateView (Scene.h:26, :37) */
 int rt_scene_set_camera(rt_scene* scene, const rt_camera* cam);

@@ -150,13 +150,13 @@ def rng_floats(seed, sample, pixel, stream, n):
 class Scene:
     """Scene::init + Scene::build on the GPU (Scene.h:150, :92)."""
 
-    def __init__(self, s: SceneData, device_build: bool = False):
+    def __init__(self, s: SceneData, device_build=None):   # None: the library's default (device), False: host build
         self.L = lib()
         self.data = s
         self.m = Marshalled(s)
         d = self.m.desc()
         h = C.c_void_p()
-        _check(self.L.rt_scene_create_ex(C.byref(d), C.c_uint32(1 if device_build else 0), C.byref(h)), "rt_scene_create")
+        _check(self.L.rt_scene_create_ex(C.byref(d), C.c_uint32(0 if device_build is None else (1 if device_build else 2)), C.byref(h)), "rt_scene_create")
         self.h = h
         self.width, self.height, self.ntris = s.width, s.height, s.ntris
         if s.cam_P is not None:

@@ -165,7 +165,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) { retu
 
 extern "C" int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_scene** out) {
     if (!desc || !out) { rt_set_error("rt_scene_create: NULL argument"); return RT_ERR_INVALID; }
-    if (flags & ~(uint32_t)RT_SCENE_BUILD_DEVICE) { rt_set_error("rt_scene_create_ex: unknown flag"); return RT_ERR_INVALID; }
+    if (flags != 0u && flags != RT_SCENE_BUILD_DEVICE && flags != RT_SCENE_BUILD_HOST) { rt_set_error("rt_scene_create_ex: flags must be 0, RT_SCENE_BUILD_DEVICE or RT_SCENE_BUILD_HOST"); return RT_ERR_INVALID; }
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -174,7 +174,7 @@ extern "C" int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_
     }
     rt_scene* s = new rt_scene();
     std::string err;
-    if (!host_scene_build(*desc, s->host, err, (flags & RT_SCENE_BUILD_DEVICE) ? device_bvh2_build : nullptr)) {
+    if (!host_scene_build(*desc, s->host, err, flags == RT_SCENE_BUILD_HOST ? nullptr : device_bvh2_build)) {
         rt_set_error("rt_scene_create: " + err); delete s; return RT_ERR_INVALID;
     }
     int rc = RT_OK;

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 def both(s):
-    return api.Scene(s), api.Scene(s, device_build=True)
+    return api.Scene(s, device_build=False), api.Scene(s, device_build=True)
 
 
 @pytest.mark.parametrize("make", [
@@ -49,7 +49,7 @@ def test_tiny_scenes(n):
 
 def test_full_size_bathroom_build_and_time():
     s = scenes.interior("bathroom", 1.0, 1920, 1080)
-    t = time.perf_counter(); h = api.Scene(s); th = time.perf_counter() - t
+    t = time.perf_counter(); h = api.Scene(s, device_build=False); th = time.perf_counter() - t
     t = time.perf_counter(); d = api.Scene(s, device_build=True); td = time.perf_counter() - t
     print(f"scene create: host build {th:.2f} s, device build {td:.2f} s (n_tris {s.ntris})")
     assert h.info()["bvh2_nodes"] == d.info()["bvh2_nodes"] and h.info()["wide_nodes"] == d.info()["wide_nodes"]
