@@ -74,7 +74,7 @@ def main():
     warm_calls = (Wm + K - 1) // K if Wm > 0 else 0
     for i in range(warm_calls):
         rt.render(api.PATH, K, seed, base + i * K)
-    rt.sync()
+        rt.sync()   # (also keeps rt_render from merging consecutive warm-up calls into one bigger batch)
     if world > 1:
         dist.all_reduce(film)  # warm-up of the film reduction too: RCCL sets up its channels / buffers on the first call of a size
         torch.cuda.synchronize()
