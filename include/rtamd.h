@@ -8,10 +8,12 @@
  * Conventions: plain pointers and sizes, no C++ or torch types; every call
  * returns RT_OK (0) or a negative rt_status and leaves a message retrievable
  * with rt_last_error() (the reference itself only prints / exit(0)s).  Host
- * buffers passed in are copied; the caller keeps ownership.  A scene is
- * immutable after creation and may be traversed from several host threads;
- * a renderer must be driven from one thread at a time (RayTracer::render is
- * called serially from main, Main.cpp:119).  All device memory is owned by the
+ * buffers passed in are copied; the caller keeps ownership.  A scene's
+ * geometry is immutable after creation and may be traversed (rt_intersect_*)
+ * from several host threads; a renderer must be driven from one thread at a
+ * time (RayTracer::render is called serially from main, Main.cpp:119), and
+ * rt_scene_set_camera / rt_counters_enable / creating or destroying a
+ * renderer of a scene must not overlap calls on that scene's renderers.  All device memory is owned by the
  * opaque handles and lives on the HIP device current at creation time.
  */
 #ifndef RTAMD_H
