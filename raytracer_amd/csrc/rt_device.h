@@ -505,7 +505,10 @@ __device__ __forceinline__ bool rt_visible_begin(const DScene& S, f3 p1, f3 p2, 
 //   Source: bool next(uint32_t& begin, uint32_t& end) -- wave-uniform grant of items [begin, end), false when drained
 // Which lane traces which item only affects speed: every item is loaded, traced and retired by exactly one lane.
 #ifndef RT_REFILL_IDLE
-#define RT_REFILL_IDLE 16
+#define RT_REFILL_IDLE 32
+#endif
+#ifndef RT_REFILL_IDLE_ANY
+#define RT_REFILL_IDLE_ANY RT_REFILL_IDLE
 #endif
 
 // Tail: once the source is drained a wave is left with its slowest walks -- a few rays that take 1000+ steps where the mean
@@ -536,7 +539,7 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
     for (;;) {
         unsigned long long idle = __ballot(!busy);
         uint32_t nidle = (uint32_t)__popcll(idle);
-        if (drained ? (nidle == 64u) : (nidle >= (uint32_t)RT_REFILL_IDLE)) {
+        if (drained ? (nidle == 64u) : (nidle >= (uint32_t)(ANY ? RT_REFILL_IDLE_ANY : RT_REFILL_IDLE))) {
             if (done) { job.retire(item, w, visible); done = false; }
             if (drained) break;
             if (pb >= pe) {
