@@ -170,6 +170,13 @@ __device__ __forceinline__ bool rt_box_exact(f3 lo, f3 hi, f3 o, f3 inv, float& 
 __device__ __forceinline__ bool rt_ray_is_tame(f3 inv) {
     return (fabsf(inv.x) < 1e18f) && (fabsf(inv.y) < 1e18f) && (fabsf(inv.z) < 1e18f);
 }
+// Beyond that there are rays no renderer shoots but a caller can pass: NaN / inf / 1e38 in the origin or the direction.  Their
+// slab products overflow or are NaN in ways the padded culling was not derived for (it assumes finite arithmetic), so they
+// take the reference-order walk, which is upstream's own sequence of operations.  False for NaN (every comparison fails).
+__device__ __forceinline__ bool rt_ray_is_moderate(f3 o, f3 dir) {
+    return (fabsf(o.x) < 1e18f) && (fabsf(o.y) < 1e18f) && (fabsf(o.z) < 1e18f) &&
+           (fabsf(dir.x) < 1e18f) && (fabsf(dir.y) < 1e18f) && (fabsf(dir.z) < 1e18f);
+}
 
 // ---- reference-order walk over the binary tree: BVHNode::traverse / traverseVisible (Geometry.h:441-490)
 // as an explicit-stack DFS (left before right, no ordering, no distance culling).
@@ -470,9 +477,10 @@ __device__ __forceinline__ bool rt_closest_begin(const DScene& S, f3 o, f3 dir, 
     // boxes the reference would have walked through on the way.
     if (mode == 0 && dir.x == 0.0f && dir.y == 0.0f && dir.z == 0.0f) return true;
     f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-    if (mode == 0 && rt_ray_is_tame(inv)) { rt_walk_init(S, w, o, dir, inv, 0.0f); return false; }
+    const bool moderate = rt_ray_is_moderate(o, dir);
+    if (mode == 0 && moderate && rt_ray_is_tame(inv)) { rt_walk_init(S, w, o, dir, inv, 0.0f); return false; }
     if (COUNT) cexact++;
-    if (mode == 0) rt_walk_exact<false, COUNT>(S, o, dir, 0.0f, w.best, spill2, gstride, cn, ct);
+    if (mode == 0 && moderate) rt_walk_exact<false, COUNT>(S, o, dir, 0.0f, w.best, spill2, gstride, cn, ct);
     else rt_walk_reference<false, COUNT>(S, o, dir, 0.0f, w.best, spill2, gstride, cn, ct);
     return true;
 }
@@ -487,10 +495,11 @@ __device__ __forceinline__ bool rt_visible_begin(const DScene& S, f3 p1, f3 p2, 
     visible = true;
     if (S.root_ref == RT_REF_EMPTY) return true;
     f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-    if (mode == 0 && rt_ray_is_tame(inv)) { rt_walk_init(S, w, o, dir, inv, maxT); return false; }
+    const bool moderate = rt_ray_is_moderate(o, dir);
+    if (mode == 0 && moderate && rt_ray_is_tame(inv)) { rt_walk_init(S, w, o, dir, inv, maxT); return false; }
     if (COUNT) cexact++;
     HitRec dummy;
-    visible = mode == 0 ? rt_walk_exact<true, COUNT>(S, o, dir, maxT, dummy, spill2, gstride, cn, ct)
+    visible = (mode == 0 && moderate) ? rt_walk_exact<true, COUNT>(S, o, dir, maxT, dummy, spill2, gstride, cn, ct)
                         : rt_walk_reference<true, COUNT>(S, o, dir, maxT, dummy, spill2, gstride, cn, ct);
     return true;
 }

@@ -81,6 +81,39 @@ def test_edge_cases():
         so.close()
 
 
+def test_hostile_rays_match_the_compiled_reference():
+    """Rays no renderer should produce but a caller can: NaN / inf components, exact zeros, denormals, huge magnitudes, segments
+    of zero and sub-epsilon length.  Whatever upstream's arithmetic makes of them (comparisons with NaN reject nothing, Min/Max
+    are ternaries) is the answer; the GPU must give it bit for bit -- against the compiled reference when its build travelled
+    with the tree, else against the oracle."""
+    s = scenes.interior("bathroom", 0.15, 64, 36)
+    sc = api.Scene(s)
+    ref = orc.RefScene(s) if orc.have_ref() else orc.OracleScene(s)
+    rng = np.random.default_rng(12)
+    base = scenes.bounce_rays(s, 20000, 4).copy()
+    specials = np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 1e-45, -1e-45, 1e-38, 3e38, -3e38, 1.0, -1.0], np.float32)
+    rays = base.copy()
+    for k in range(len(rays)):                      # one to three components replaced by a special value
+        for c in rng.choice(6, size=rng.integers(1, 4), replace=False):
+            rays[k, c] = specials[rng.integers(len(specials))]
+    axis = base[:3000].copy()                       # axis-parallel directions with exact zeros, origins on vertex coordinates
+    axis[:, 3:] = 0.0
+    axis[np.arange(3000), 3 + rng.integers(0, 3, 3000)] = rng.choice(np.array([1.0, -1.0, 1e-30, 2.5], np.float32), 3000)
+    v = s.verts[:, :, :3].reshape(-1, 3)
+    axis[:, :3] = v[rng.integers(0, len(v), 3000)]
+    rays = np.concatenate([rays, axis]).astype(np.float32)
+    got, want = sc.traverse(rays), ref.traverse(rays)
+    assert_hits_bitexact(got, want, "hostile rays", nan_payload_free=True)
+    segs = scenes.shadow_segments(s, 20000, 9).copy()
+    segs[:2000, 3:] = segs[:2000, :3]                                          # zero length: dir = 0/0
+    segs[2000:4000, 3:] = segs[2000:4000, :3] + np.float32(1e-4) * rng.normal(size=(2000, 3)).astype(np.float32)   # shorter than 2 eps
+    for k in range(4000, 12000):
+        for c in rng.choice(6, size=rng.integers(1, 3), replace=False):
+            segs[k, c] = specials[rng.integers(len(specials))]
+    assert np.array_equal(sc.visible(segs), ref.visible(segs))
+    sc.close()
+
+
 @pytest.mark.parametrize("make,label", [(scenes.bathroom, "bathroom"), (scenes.living_room, "living-room")])
 def test_full_size_wide_walk_equals_reference_order_walk(make, label):
     """At the bench's full size (BASELINE configs 3-4) the oracle is too slow; the size-independent property is that the

@@ -25,15 +25,19 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-def assert_hits_bitexact(got, want, what=""):
-    """hit/miss, triangle ID, t, alpha, beta, gamma identical bit for bit (no tolerance, no exclusions)."""
+def assert_hits_bitexact(got, want, what="", nan_payload_free=False):
+    """hit/miss, triangle ID, t, alpha, beta, gamma identical bit for bit (no tolerance, no exclusions).
+    nan_payload_free: a NaN matches a NaN whatever its sign / payload bits (x86 makes -qNaN from inf - inf, the GPU +qNaN)."""
+    def same(a, b):
+        eq = bits(a) == bits(b)
+        return eq | (np.isnan(a) & np.isnan(b)) if nan_payload_free else eq
     hg, hw = got["t"] < 3e38, want["t"] < 3e38
     assert (hg == hw).all(), f"{what}: hit/miss differs on {int((hg != hw).sum())} rays"
-    assert (bits(got["t"]) == bits(want["t"])).all(), f"{what}: t bits differ on {int((bits(got['t']) != bits(want['t'])).sum())} rays"
+    assert same(got["t"], want["t"]).all(), f"{what}: t bits differ on {int((~same(got['t'], want['t'])).sum())} rays"
     m = hw
     assert (got["ID"][m] == want["ID"][m]).all(), f"{what}: triangle ID differs on {int((got['ID'][m] != want['ID'][m]).sum())} rays"
     for k in ("alpha", "beta", "gamma"):
-        assert (bits(got[k][m]) == bits(want[k][m])).all(), f"{what}: {k} bits differ"
+        assert same(got[k][m], want[k][m]).all(), f"{what}: {k} bits differ on {int((~same(got[k][m], want[k][m])).sum())} rays"
 
 
 def rel_mse(img, ref, eps=1e-2):
