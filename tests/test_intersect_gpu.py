@@ -114,6 +114,37 @@ def test_hostile_rays_match_the_compiled_reference():
     sc.close()
 
 
+def test_hostile_scene_matches_the_compiled_reference():
+    """Geometry no exporter should write but the ABI accepts: zero-area triangles (two equal vertices, collinear vertices),
+    exact duplicates (equal centroids: upstream's split fails and leaves a many-triangle leaf), coordinates of 1e15 next to unit
+    ones, triangles thinner than a float ulp of their position."""
+    base = scenes.random_soup(6000, seed=5)
+    v = base.verts.copy()
+    rng = np.random.default_rng(3)
+    idx = rng.permutation(len(v))
+    v[idx[:400], 1, :3] = v[idx[:400], 0, :3]                                         # two equal vertices
+    v[idx[400:800], 2, :3] = (v[idx[400:800], 0, :3] + v[idx[400:800], 1, :3]) * np.float32(0.5)   # collinear
+    v[idx[800:1400]] = v[idx[1400:1460]].repeat(10, axis=0)                             # ten copies each of 60 triangles
+    v[idx[1460:1500], :, :3] *= np.float32(1e15)                                       # far outliers
+    v[idx[1500:1600], 1, :3] = v[idx[1500:1600], 0, :3] + np.float32(1e-9)             # below the ulp of the position
+    s = scenes.SceneData("hostile", v, base.tri_mat.copy(), base.materials, base.textures)
+    scenes.set_camera(s, (0, 0, 12), (0, 0, 0), (0, 1, 0), 45.0, 64, 64)
+    ref = orc.RefScene(s) if orc.have_ref() else orc.OracleScene(s)
+    for db in (False, True):
+        sc = api.Scene(s, device_build=db)
+        if not db:
+            host_order = sc.leaf_order()
+        else:
+            assert np.array_equal(sc.leaf_order(), host_order)
+        ro = ref.leaf_order()
+        assert np.array_equal(sc.leaf_order(), ro[0] if isinstance(ro, tuple) else ro)
+        rays = np.concatenate([scenes.primary_rays(s, 20000, 1), scenes.bounce_rays(base, 40000, 2)])
+        assert_hits_bitexact(sc.traverse(rays), ref.traverse(rays), f"hostile scene (device_build={db})", nan_payload_free=True)
+        segs = scenes.shadow_segments(base, 40000, 3)
+        assert np.array_equal(sc.visible(segs), ref.visible(segs))
+        sc.close()
+
+
 @pytest.mark.parametrize("make,label", [(scenes.bathroom, "bathroom"), (scenes.living_room, "living-room")])
 def test_full_size_wide_walk_equals_reference_order_walk(make, label):
     """At the bench's full size (BASELINE configs 3-4) the oracle is too slow; the size-independent property is that the
