@@ -169,6 +169,33 @@ def test_tonemap_on_device_matches_film_tonemap():
     rt.close(); sc.close()
 
 
+@pytest.mark.parametrize("w,h", [(2, 2), (3, 5), (9, 2), (130, 7)], ids=["2x2", "3x5", "9x2", "130x7"])
+def test_odd_film_sizes_same_seed(w, h):
+    """Films that are not a multiple of the 8x8 generation tile, down to the 2x2 minimum: every integrator and a filtered
+    film against the oracle, same seeds."""
+    s = scenes.cornell(w, h)
+    o = orc.OracleScene(s)
+    sc = api.Scene(s)
+    rt = api.RayTracer(sc)
+    want, _ = o.render(0, 16, seed=4, threads=4)
+    rt.render(api.PATH, 16, 4, 0); got, _ = rt.film()
+    assert got.shape == (h, w, 3) and np.allclose(got, want, rtol=2e-3, atol=1e-4)
+    rt.clear(); rt.setFilter(api.FILTER_MITCHELL); o.set_filter(2)
+    want, _ = o.render(0, 16, seed=4, threads=4)
+    rt.render(api.PATH, 16, 4, 0); got, _ = rt.film()
+    assert np.allclose(got, want, rtol=2e-3, atol=1e-4)
+    rt.clear(); rt.setFilter(api.FILTER_BOX); o.set_filter(0)
+    want, _ = o.render(1, 64, seed=6, threads=4)
+    rt.render(api.LIGHT, 64, 6, 0); got, _ = rt.film()
+    assert abs(got.sum(dtype=np.float64) / max(want.sum(dtype=np.float64), 1e-30) - 1) < 1e-2
+    rt.clear()
+    want = o.mlt_render(1, seed=8)
+    rt.render(api.MLT, 1, 8, 0); got, _ = rt.film()
+    assert abs(got.sum(dtype=np.float64) / want.sum(dtype=np.float64) - 1) < 1e-2
+    assert rt.tonemap().shape == (h, w, 3)
+    rt.close(); sc.close()
+
+
 def test_4k_render_sample_partition_composes():
     """BASELINE config 4 shape: bathroom at 3840x2160 (2 spp per batch).  Size-independent properties: two "ranks" with disjoint
     sample ranges sum to the single-renderer film, the film is finite where the frame has no specular fireflies, and
