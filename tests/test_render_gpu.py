@@ -455,3 +455,48 @@ def test_bsdf_probes_extreme_parameters():
             err = np.abs(got[fin] - want[fin]) / (1e-3 + np.abs(want[fin]))
             assert (err < 1e-3).mean() > 0.99, (mat - first, what, float(np.quantile(err, 0.999)))
     sc.close()
+
+
+def test_hostile_scene_renders_like_the_oracle():
+    """A scene with zero-area triangles (an emissive one among them: pdf = 1 / area = inf), zero and NaN shading normals, NaN and
+    1e30 texture coordinates and every material class: the integrators must finish, count the same rays as the oracle, and put
+    their non-finite pixels where the oracle's are."""
+    from raytracer_amd.scenes import Material, CONDUCTOR, GLASS, DIELECTRIC, PLASTIC, ORENNAYAR, MIRROR, DIFFUSE
+    s = scenes.cornell(48, 48, with_specular=True)
+    v = s.verts.copy(); tm = s.tri_mat.copy()
+    rng = np.random.default_rng(8)
+    n = len(v)
+    extra = v[rng.integers(0, n, 60)].copy()
+    extra[:, :, :3] = extra[:, :1, :3] + rng.uniform(-0.3, 0.3, size=(60, 3, 3)).astype(np.float32)   # small floating triangles
+    extra[:10, 1, :3] = extra[:10, 0, :3]                 # zero area
+    extra[10:20, :, 3:6] = 0.0                            # zero shading normals
+    extra[20:25, :, 3:6] = np.nan
+    extra[25:30, :, 6:8] = np.nan                         # texture coordinates
+    extra[30:35, :, 6:8] = 1e30
+    s.materials = list(s.materials) + [Material(CONDUCTOR, 0, roughness=0.1, eta=(0.2, 0.9, 1.1), k=(3.9, 2.4, 2.1)), Material(DIELECTRIC, 0, int_ior=1.5, roughness=0.2),
+                                       Material(PLASTIC, 0, int_ior=1.5, roughness=0.1), Material(ORENNAYAR, 0, sigma=0.5),
+                                       Material(DIFFUSE, 0, emission=(5.0, 5.0, 5.0))]
+    m0 = len(s.materials) - 5
+    em = np.concatenate([rng.integers(m0, m0 + 4, 55), np.full(5, m0 + 4)]).astype(np.uint32)
+    em[:2] = m0 + 4                                       # two zero-area emitters
+    s.verts = np.concatenate([v, extra]).astype(np.float32); s.tri_mat = np.concatenate([tm, em]).astype(np.uint32)
+    o = orc.OracleScene(s)
+    sc = api.Scene(s)
+    rt = api.RayTracer(sc)
+    for mode, omode, spp in ((api.PATH, 0, 8), (api.LIGHT, 1, 8), (api.DIRECT, 12, 1), (api.AOV_NORMAL, 11, 1)):
+        rt.clear(); rt.counters(reset=True)
+        want, st = o.render(omode, spp, seed=3, threads=8)
+        rt.render(mode, spp, 3, 0); got, _ = rt.film(); cnt = rt.counters()
+        fw, fg = np.isfinite(want).all(axis=2), np.isfinite(got).all(axis=2)
+        assert (fw ^ fg).mean() < 2e-3, (mode, int((fw ^ fg).sum()))
+        assert abs(cnt["closest_rays"] / st["closest_rays"] - 1) < 1e-2, mode
+        both = fw & fg
+        a, b = got[both].astype(np.float64), want[both].astype(np.float64)
+        close = (np.abs(a - b) <= 2e-3 * np.maximum(np.abs(a), np.abs(b)) + 1e-4).all(axis=1)
+        if mode != api.LIGHT:
+            assert close.mean() > 0.995, (mode, close.mean())
+    n_v = o.vpl_trace(8, seed=2)
+    assert rt.traceVPLs(8, 2) == n_v
+    rt.clear(); rt.render(api.RADIOSITY, 2, 3, 0); rt.render(api.MLT, 1, 3, 2)
+    assert rt.getSPP() == 3 and rt.film()[0].shape == (48, 48, 3)
+    rt.close(); sc.close()
