@@ -1437,10 +1437,14 @@ static int render_now(rt_renderer* r, int mode, int spp, uint64_t seed, uint64_t
     int done = 0;
     if ((mode == RT_MODE_PATH || mode == RT_MODE_LIGHT) && spp >= 2 && RT_LANES > 1) {
         // at least two batches, alternating between the two lanes (streams).  Path tracing chains its film accumulation by
-        // an event (fixed fp32 sum order); the light tracer's splats are atomics and need no order.
+        // an event (fixed fp32 sum order); the light tracer's splats are atomics and need no order (PSSMLT on two lanes measured no faster).
         int rc = ensure_other_lane(r);
         if (rc) return rc;
         uint32_t nb = std::max<uint32_t>(2u, ((uint32_t)spp + bmax - 1) / bmax);
+        // lane 1 starts behind whatever lane 0 already holds (a film clear, an earlier render): its splats are atomics on the
+        // same film and would otherwise be free to land before a memset queued ahead of this render
+        RT_HIP(hipEventRecord(r->acc_event, r->stream));
+        RT_HIP(hipStreamWaitEvent(r->other.stream, r->acc_event, 0));
         for (uint32_t i = 0; i < nb; i++) {
             uint32_t b = (uint32_t)spp / nb + (i < (uint32_t)spp % nb ? 1u : 0u);
             use_lane(r, (int)(i & 1u));
