@@ -345,34 +345,84 @@ struct DevBuf {
 };
 }  // namespace
 
+// Host-buffer batches.  Up to RT_HOST_CHUNK items go up, through the kernel and back in one piece; larger batches are cut into
+// chunks on three streams so that chunk i+1 is on its way up and chunk i-1 on its way down while chunk i is traced (the
+// caller's memory is pageable, so the copies are what bounds this path: 44 B per closest-hit ray over PCIe; pinning it
+// for the call with hipHostRegister measured no faster).  Device memory stays at two chunks whatever the batch size.
+#define RT_HOST_CHUNK ((size_t)1 << 21)
+namespace {
+struct HostPipe {
+    hipStream_t up = nullptr, run = nullptr, down = nullptr;
+    hipEvent_t in_ready[2] = { nullptr, nullptr }, traced[2] = { nullptr, nullptr }, out_read[2] = { nullptr, nullptr };
+    DevBuf din[2], dout[2];
+    ~HostPipe() {
+        for (hipStream_t st : { up, run, down }) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+        for (int k = 0; k < 2; k++) for (hipEvent_t e : { in_ready[k], traced[k], out_read[k] }) if (e) (void)hipEventDestroy(e);
+    }
+};
+template <class In, class Out, class Launch>
+int host_batch(const In* in, size_t n, Out* out, Launch launch) {
+    if (n <= RT_HOST_CHUNK) {
+        DevBuf di, d_o;
+        RT_HIP(hipMalloc(&di.p, n * sizeof(In)));
+        RT_HIP(hipMalloc(&d_o.p, n * sizeof(Out)));
+        RT_HIP(hipMemcpy(di.p, in, n * sizeof(In), hipMemcpyHostToDevice));
+        int rc = launch((const In*)di.p, n, (Out*)d_o.p, nullptr);
+        if (rc) return rc;
+        RT_HIP(hipDeviceSynchronize());
+        RT_HIP(hipMemcpy(out, d_o.p, n * sizeof(Out), hipMemcpyDeviceToHost));
+        return RT_OK;
+    }
+    HostPipe p;
+    RT_HIP(hipStreamCreate(&p.up)); RT_HIP(hipStreamCreate(&p.run)); RT_HIP(hipStreamCreate(&p.down));
+    for (int k = 0; k < 2; k++) {
+        RT_HIP(hipEventCreateWithFlags(&p.in_ready[k], hipEventDisableTiming)); RT_HIP(hipEventCreateWithFlags(&p.traced[k], hipEventDisableTiming));
+        RT_HIP(hipEventCreateWithFlags(&p.out_read[k], hipEventDisableTiming));
+        RT_HIP(hipMalloc(&p.din[k].p, RT_HOST_CHUNK * sizeof(In))); RT_HIP(hipMalloc(&p.dout[k].p, RT_HOST_CHUNK * sizeof(Out)));
+    }
+    const size_t chunks = (n + RT_HOST_CHUNK - 1) / RT_HOST_CHUNK;
+    for (size_t i = 0; i <= chunks; i++) {
+        if (i < chunks) {
+            const int k = (int)(i & 1);
+            const size_t off = i * RT_HOST_CHUNK, m = std::min(RT_HOST_CHUNK, n - off);
+            if (i >= 2) RT_HIP(hipStreamWaitEvent(p.up, p.traced[k], 0));        // chunk i-2 no longer reads this input buffer
+            RT_HIP(hipMemcpyAsync(p.din[k].p, in + off, m * sizeof(In), hipMemcpyHostToDevice, p.up));
+            RT_HIP(hipEventRecord(p.in_ready[k], p.up));
+            RT_HIP(hipStreamWaitEvent(p.run, p.in_ready[k], 0));
+            if (i >= 2) RT_HIP(hipStreamWaitEvent(p.run, p.out_read[k], 0));    // chunk i-2's results have left this output buffer
+            int rc = launch((const In*)p.din[k].p, m, (Out*)p.dout[k].p, p.run);
+            if (rc) return rc;
+            RT_HIP(hipEventRecord(p.traced[k], p.run));
+        }
+        if (i >= 1) {   // results of the previous chunk come down while this one is traced
+            const int k = (int)((i - 1) & 1);
+            const size_t off = (i - 1) * RT_HOST_CHUNK, m = std::min(RT_HOST_CHUNK, n - off);
+            RT_HIP(hipStreamWaitEvent(p.down, p.traced[k], 0));
+            RT_HIP(hipMemcpyAsync(out + off, p.dout[k].p, m * sizeof(Out), hipMemcpyDeviceToHost, p.down));
+            RT_HIP(hipEventRecord(p.out_read[k], p.down));
+        }
+    }
+    RT_HIP(hipStreamSynchronize(p.up)); RT_HIP(hipStreamSynchronize(p.run)); RT_HIP(hipStreamSynchronize(p.down));
+    return RT_OK;
+}
+}  // namespace
+
 extern "C" int rt_intersect_closest(rt_scene* s, const rt_ray* rays, size_t n, rt_hit* out, int mode) {
     if (!s || (n && (!rays || !out))) { rt_set_error("rt_intersect_closest: NULL argument"); return RT_ERR_INVALID; }
     if (check_mode(mode)) return RT_ERR_INVALID;
     if (n == 0) return RT_OK;
-    DevBuf in, o;
-    RT_HIP(hipMalloc(&in.p, n * sizeof(rt_ray)));
-    RT_HIP(hipMalloc(&o.p, n * sizeof(rt_hit)));
-    RT_HIP(hipMemcpy(in.p, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
-    int rc = rt_intersect_closest_dev(s, (const rt_ray*)in.p, n, (rt_hit*)o.p, mode, nullptr);
-    if (rc) return rc;
-    RT_HIP(hipDeviceSynchronize());
-    RT_HIP(hipMemcpy(out, o.p, n * sizeof(rt_hit), hipMemcpyDeviceToHost));
-    return RT_OK;
+    return host_batch(rays, n, out, [&](const rt_ray* d_in, size_t m, rt_hit* d_out, hipStream_t st) {
+        return rt_intersect_closest_dev(s, d_in, m, d_out, mode, st);
+    });
 }
 
 extern "C" int rt_intersect_any(rt_scene* s, const rt_segment* segs, size_t n, uint8_t* out, int mode) {
     if (!s || (n && (!segs || !out))) { rt_set_error("rt_intersect_any: NULL argument"); return RT_ERR_INVALID; }
     if (check_mode(mode)) return RT_ERR_INVALID;
     if (n == 0) return RT_OK;
-    DevBuf in, o;
-    RT_HIP(hipMalloc(&in.p, n * sizeof(rt_segment)));
-    RT_HIP(hipMalloc(&o.p, n));
-    RT_HIP(hipMemcpy(in.p, segs, n * sizeof(rt_segment), hipMemcpyHostToDevice));
-    int rc = rt_intersect_any_dev(s, (const rt_segment*)in.p, n, (uint8_t*)o.p, mode, nullptr);
-    if (rc) return rc;
-    RT_HIP(hipDeviceSynchronize());
-    RT_HIP(hipMemcpy(out, o.p, n, hipMemcpyDeviceToHost));
-    return RT_OK;
+    return host_batch(segs, n, out, [&](const rt_segment* d_in, size_t m, uint8_t* d_out, hipStream_t st) {
+        return rt_intersect_any_dev(s, d_in, m, d_out, mode, st);
+    });
 }
 
 extern "C" int rt_generate_rays(rt_scene* s, const float* xy, size_t n, rt_ray* out) {

@@ -81,6 +81,22 @@ def test_edge_cases():
         so.close()
 
 
+def test_large_host_batches_are_pipelined_and_identical():
+    """Host-buffer batches above 2 Mi items are cut into chunks that overlap copy-in, trace and copy-out on three streams: the
+    results must be those of the same rays passed in small calls (ragged last chunk included)."""
+    s = scenes.interior("bathroom", 0.3, 64, 36)
+    sc = api.Scene(s)
+    n = (5 << 20) + 12345
+    rays = scenes.bounce_rays(s, n, 21)
+    segs = scenes.shadow_segments(s, n, 22)
+    big_h, big_v = sc.traverse(rays), sc.visible(segs)
+    step = 1 << 20
+    for a in range(0, n, step):
+        assert np.array_equal(big_h[a:a + step].view(np.uint8), sc.traverse(rays[a:a + step]).view(np.uint8)), a
+        assert np.array_equal(big_v[a:a + step], sc.visible(segs[a:a + step])), a
+    sc.close()
+
+
 def test_hostile_rays_match_the_compiled_reference():
     """Rays no renderer should produce but a caller can: NaN / inf components, exact zeros, denormals, huge magnitudes, segments
     of zero and sub-epsilon length.  Whatever upstream's arithmetic makes of them (comparisons with NaN reject nothing, Min/Max
