@@ -385,6 +385,7 @@ inline Texture loadTextureFile(const std::string& filename) {
 struct Loaded {   // everything Scene::init / Camera::init need, before any device is involved
     std::vector<Triangle> triangles; std::vector<rt_material> materials; std::vector<Texture> textures; rt_background background;
     Matrix P, V; int width = 0, height = 0;
+    Vec3 from, to, up;
 };
 inline rt_material baseMaterial(uint32_t type, int tex) {
     rt_material m; memset(&m, 0, sizeof(m));
@@ -403,6 +404,7 @@ inline Loaded loadGEMScene(const std::string& sceneName) {
     sp.find("to").getValuesAsVector3(to.x, to.y, to.z);
     sp.find("up").getValuesAsVector3(up.x, up.y, up.z);
     L.V = Matrix::lookAt(from, to, up).invert();
+    L.from = from; L.to = to; L.up = up;
     if (sp.find("flipX").getValue(0) == 1) L.P.a(0, 0) = -L.P.a(0, 0);
     std::map<std::string, int> textureManager;
     auto loadTexture = [&](const std::string& filename) {   // SceneLoader.h:92-102
@@ -491,11 +493,21 @@ inline Scene* loadScene(std::string sceneName, int width = 1024, int height = 10
         scene = new Scene();
         scene->camera.init(L.P, L.width, L.height);
         scene->camera.updateView(L.V);
+        viewcamera.from = L.from; viewcamera.to = L.to; viewcamera.up = L.up;   // SceneLoader.h:261-264
+        viewcamera.camera = &scene->camera; viewcamera.scene = scene;
         scene->init(std::move(L.triangles), L.materials, L.textures, L.background);
     } else if (exists(sceneName + "/scene.rtsc")) scene = readRTSC(sceneName + "/scene.rtsc");
     else if (sceneName.size() > 5 && sceneName.compare(sceneName.size() - 5, 5, ".rtsc") == 0 && exists(sceneName)) scene = readRTSC(sceneName);
     else if (sceneName == "cornell-box") scene = cornellBox(width, height);
     else throw std::runtime_error("loadScene: no scene '" + sceneName + "' (expected <name>/scene.json, <name>/scene.rtsc, an .rtsc file, or cornell-box)");
+    if (viewcamera.scene != scene) {   // a flat export carries the matrices only: V's columns are left, up', back, from (Core.h:460)
+        const Matrix& V = scene->camera.camera;
+        viewcamera.from = Vec3(V.m[3], V.m[7], V.m[11]);
+        viewcamera.to = viewcamera.from - Vec3(V.m[2], V.m[6], V.m[10]);
+        viewcamera.up = Vec3(V.m[1], V.m[5], V.m[9]);
+        viewcamera.camera = &scene->camera; viewcamera.scene = scene;
+    }
+    viewcamera.movespeed = scene->boundsDiagonal() * 0.05f;   // SceneLoader.h:284
     if (build) {
         try { scene->build(); } catch (...) { delete scene; throw; }
     }

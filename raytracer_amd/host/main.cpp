@@ -3,6 +3,7 @@
 // Extra arguments: -type (RayTracer::type, Renderer.h:372), -width/-height (built-in cornell-box only), -seed,
 // -sppPerCall (samples added per render() call), -vpls (traceVPLs before type 4), -png (also write the tonemapped PNG),
 // -filter box|gaussian|mitchell (the film's ImageFilter, Renderer.h:61),
+// -keys WSADEQ... (scripted key presses of Main.cpp:87-116, one per frame: move the fly camera and clear the film),
 // -dump file.rtsc (load the scene, write it as a flat file and stop: checks the loaders without a GPU).
 #include <chrono>
 #include <iostream>
@@ -15,7 +16,7 @@ int main(int argc, char* argv[]) {
     std::string filename = "radiosity.hdr";   // upstream's default name (Main.cpp:29)
     unsigned int SPP = 8192;
     int type = 0, width = 1024, height = 1024, perCall = 1, vpls = 0, png = 0, filter = RT_FILTER_BOX;
-    std::string dump;
+    std::string dump, keys;
     unsigned long long seed = 1;
     std::unordered_map<std::string, std::string> args;
     for (int i = 1; i < argc; ++i) {
@@ -36,6 +37,7 @@ int main(int argc, char* argv[]) {
             else if (pair.first == "-seed") seed = std::stoull(pair.second);
             else if (pair.first == "-sppPerCall") perCall = std::stoi(pair.second);
             else if (pair.first == "-vpls") vpls = std::stoi(pair.second);
+            else if (pair.first == "-keys") keys = pair.second;
             else if (pair.first == "-filter") {
                 if (pair.second == "box") filter = RT_FILTER_BOX;
                 else if (pair.second == "gaussian") filter = RT_FILTER_GAUSSIAN;
@@ -47,8 +49,20 @@ int main(int argc, char* argv[]) {
             else std::cerr << "Warning: unknown argument '" << pair.first << "'\n";
         }
         if (perCall < 1) perCall = 1;
+        auto press = [](char key) {   // Main.cpp:87-116
+            switch (key) {
+            case 'W': rtamd::viewcamera.forward(); break;
+            case 'S': rtamd::viewcamera.back(); break;
+            case 'A': rtamd::viewcamera.left(); break;
+            case 'D': rtamd::viewcamera.right(); break;
+            case 'E': rtamd::viewcamera.flyUp(); break;
+            case 'Q': rtamd::viewcamera.flyDown(); break;
+            default: throw std::runtime_error("-keys: W, S, A, D, E or Q");
+            }
+        };
         if (!dump.empty()) {   // loader check: parse the scene and write it back as a flat RTSC file; no device involved
             rtamd::Scene* host = rtamd::loadScene(sceneName, width, height, false);
+            for (char key : keys) press(key);   // the dumped camera is where the key presses leave it
             rtamd::saveRTSC(*host, dump);
             std::cout << "number of triangle: " << host->triangles.size() << "\n";
             delete host;
@@ -64,7 +78,10 @@ int main(int argc, char* argv[]) {
         rt.seed = seed;
         if (filter != RT_FILTER_BOX) rt.setFilter(filter);
         if (vpls > 0) rt.traceVPLs(vpls);
+        size_t frame = 0;
         while ((unsigned int)rt.getSPP() < SPP) {
+            if (frame < keys.size()) { press(keys[frame]); rt.clear(); }
+            frame++;
             rt.samplesPerCall = (int)std::min<unsigned int>((unsigned int)perCall, SPP - (unsigned int)rt.getSPP());
             auto t0 = std::chrono::steady_clock::now();
             rt.render();

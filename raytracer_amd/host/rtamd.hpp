@@ -127,6 +127,20 @@ public:
         check(rt_scene_set_camera(handle, &c), "Scene::build (camera)");
     }
     rt_scene_info info() const { rt_scene_info i; check(rt_scene_get_info(handle, &i), "Scene::info"); return i; }
+    // Upstream's renderer reads Scene::camera directly; here a changed view has to reach the device (RTCamera does this).
+    void pushCamera() { if (handle) { rt_camera c = camera.abi(); check(rt_scene_set_camera(handle, &c), "Scene::pushCamera"); } }
+    // |bounds.max - bounds.min| of Scene::init's box over all vertices (Scene.h:152-158), for RTCamera::movespeed
+    float boundsDiagonal() const {
+        if (triangles.empty()) return 0.0f;
+        Vec3 lo(3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f), hi(-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f);
+        for (const Triangle& t : triangles) for (int k = 0; k < 3; k++) {
+            const Vec3& p = t.vertices[k].p;
+            lo = Vec3(lo.x < p.x ? lo.x : p.x, lo.y < p.y ? lo.y : p.y, lo.z < p.z ? lo.z : p.z);
+            hi = Vec3(hi.x > p.x ? hi.x : p.x, hi.y > p.y ? hi.y : p.y, hi.z > p.z ? hi.z : p.z);
+        }
+        Vec3 d = hi - lo;
+        return sqrtf(d.dot(d));
+    }
 
     // IntersectionData Scene::traverse(const Ray&) (Scene.h:118); miss <=> t == FLT_MAX
     std::vector<IntersectionData> traverse(const std::vector<Ray>& rays) const {
@@ -245,12 +259,47 @@ inline void addBox(std::vector<Triangle>& out, Vec3 lo, Vec3 hi, unsigned int ma
     addQuad(out, Vec3(lo.x, hi.y, hi.z), Vec3(d.x, 0, 0), Vec3(0, 0, -d.z), Vec3(0, 1, 0), mat);
     addQuad(out, Vec3(lo.x, lo.y, lo.z), Vec3(d.x, 0, 0), Vec3(0, 0, d.z), Vec3(0, -1, 0), mat);
 }
+// RTCamera (SceneLoader.h:8-88): the fly camera Main.cpp drives with W/S/A/D/E/Q (Main.cpp:87-116).  Same steps and the same
+// Rodrigues rotation about `up`; updateCamera() rebuilds V = lookAt(from, to, up).invert(), hands it to Camera::updateView
+// and -- what upstream gets for free from sharing the Camera object -- pushes it to the device scene.
+class RTCamera {
+public:
+    Vec3 from, to, up;
+    Camera* camera = nullptr;
+    Scene* scene = nullptr;     // not upstream: whose device copy to refresh
+    float movespeed = 1.0f;
+    float rotspeed = 5.0f;
+    void forward() { Vec3 dir = (to - from).normalize() * movespeed; from = from + dir; to = from + dir; updateCamera(); }
+    void back() { Vec3 dir = (to - from).normalize() * movespeed; from = from - dir; to = from + dir; updateCamera(); }
+    void left() { turn(rotspeed * ((float)M_PI / 180.0f)); }
+    void right() { turn(-rotspeed * ((float)M_PI / 180.0f)); }
+    void flyUp() { Vec3 dir = up * movespeed; from = from + dir; to = to + dir; updateCamera(); }
+    void flyDown() { Vec3 dir = up * movespeed; from = from - dir; to = to - dir; updateCamera(); }
+    void updateCamera() {
+        Matrix V = Matrix::lookAt(from, to, up).invert();
+        if (camera) camera->updateView(V);
+        if (scene) scene->pushCamera();
+    }
+private:
+    void turn(float rad) {   // SceneLoader.h:38-69; upstream forms rotspeed * (M_PI / 180.0f) in double and narrows it here
+        Vec3 dir = (to - from).normalize();
+        float cosTheta = cosf(rad), sinTheta = sinf(rad);
+        Vec3 k = up;
+        Vec3 rotated = (dir * cosTheta) + (k.cross(dir) * sinTheta) + (k * (k.dot(dir) * (1 - cosTheta)));
+        to = from + rotated;
+        updateCamera();
+    }
+};
+inline RTCamera viewcamera;   // SceneLoader.h:90
+
 inline void setCamera(Scene* scene, Vec3 from, Vec3 to, Vec3 up, float fov, int width, int height, bool flipX = false) {
     Matrix P = Matrix::perspective(0.001f, 10000.0f, (float)width / (float)height, fov);   // SceneLoader.h:244
     if (flipX) P.a(0, 0) = -P.a(0, 0);
     Matrix V = Matrix::lookAt(from, to, up).invert();                                        // SceneLoader.h:251-252
     scene->camera.init(P, width, height);
     scene->camera.updateView(V);
+    viewcamera.from = from; viewcamera.to = to; viewcamera.up = up;   // SceneLoader.h:261-264
+    viewcamera.camera = &scene->camera; viewcamera.scene = scene;
 }
 inline Scene* cornellBox(int width, int height) {
     Scene* scene = new Scene();

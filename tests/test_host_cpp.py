@@ -56,6 +56,54 @@ def test_rtsc_export_layout(tmp_path):
     assert np.array_equal(np.frombuffer(b[-96 * nt:], np.float32).reshape(nt, 3, 8), s.verts)
 
 
+def test_rtcamera_key_presses(tmp_path):
+    """RTCamera (SceneLoader.h:8-88) as Main.cpp drives it with W/S/A/D/E/Q: the C++ mirror's view matrix after a key sequence
+    against the same steps restated here (float32, Rodrigues rotation about `up`, movespeed = 5 % of the scene diagonal)."""
+    f = np.float32
+    frm, to, up = np.array([0, 1.0, 4.4], f), np.array([0, 1.0, 0], f), np.array([0, 1, 0], f)   # the built-in box (rtamd.hpp cornellBox)
+    box = subprocess.run([_cli(), "-scene", "cornell-box", "-width", "32", "-height", "32", "-dump", str(tmp_path / "a.rtsc")], capture_output=True, text=True, timeout=60)
+    assert box.returncode == 0, box.stderr
+    s0 = abi.load_rtsc(str(tmp_path / "a.rtsc"))
+    p = s0.verts[:, :, :3].reshape(-1, 3)
+    move = f(np.sqrt(((p.max(0) - p.min(0)).astype(f) ** 2).sum(dtype=f)) * f(0.05))
+    nrm = lambda v: (v * (f(1) / np.sqrt(np.dot(v, v)))).astype(f)
+    keys = "WWADDEQSAAW"
+    for k in keys:
+        d = nrm(to - frm)
+        if k == "W": frm = frm + d * move; to = frm + d * move
+        elif k == "S": frm = frm - d * move; to = frm + d * move
+        elif k in "AD":
+            rad = f((5.0 if k == "A" else -5.0) * f(np.pi / 180.0))
+            c, sn = f(np.cos(rad)), f(np.sin(rad))
+            to = frm + (d * c + np.cross(up, d).astype(f) * sn + up * (np.dot(up, d) * (f(1) - c))).astype(f)
+        elif k == "E": frm = frm + up * move; to = to + up * move
+        elif k == "Q": frm = frm - up * move; to = to - up * move
+        frm, to = frm.astype(f), to.astype(f)
+    want = np.linalg.inv(scenes.look_at(frm, to, up).reshape(4, 4).astype(np.float64)).astype(f)
+    r = subprocess.run([_cli(), "-scene", "cornell-box", "-width", "32", "-height", "32", "-keys", keys, "-dump", str(tmp_path / "b.rtsc")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    got = np.asarray(abi.load_rtsc(str(tmp_path / "b.rtsc")).cam_V, f).reshape(4, 4)
+    assert np.allclose(got, want, atol=2e-5), (got, want)
+    assert not np.allclose(got, np.asarray(s0.cam_V, f).reshape(4, 4), atol=1e-3)
+    bad = subprocess.run([_cli(), "-scene", "cornell-box", "-keys", "X", "-dump", str(tmp_path / "c.rtsc")], capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0 and "-keys" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_cli_fly_camera_moves_the_render(tmp_path):
+    """Main.cpp:87-116 headless: a key press moves the camera and clears the film, so the saved image is the last view's."""
+    outs = []
+    for keys in ("", "WWA", "WWAD"):
+        out = tmp_path / f"k{len(keys)}.hdr"
+        r = subprocess.run([_cli(), "-scene", "cornell-box", "-width", "48", "-height", "48", "-SPP", "6", "-sppPerCall", "2", "-outputFilename", str(out)]
+                           + (["-keys", keys] if keys else []), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        outs.append(read_hdr(str(out)))
+    assert np.isfinite(outs[1]).all() and outs[1].mean() > 0
+    assert np.abs(outs[0] - outs[1]).mean() > 0.02 * outs[0].mean()      # another view
+    assert np.abs(outs[1] - outs[2]).mean() > 0.02 * outs[0].mean()
+
+
 @pytest.mark.gpu
 def test_cli_matches_python_host(tmp_path):
     s = scenes.cornell(64, 48)
