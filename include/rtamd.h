@@ -173,6 +173,10 @@ enum {
     RT_FILTER_MITCHELL = 2   /* MitchellNetravaliFilter, size 2 (Imaging.h:179) */
 };
 int rt_renderer_set_filter(rt_renderer* r, int filter);
+/* albedoFilm / normalFilm (Renderer.h:100-103) as getTileFilms fills them for a denoiser (Renderer.h:577-603): `spp` samples of
+ * RT_MODE_AOV_ALBEDO / RT_MODE_AOV_NORMAL (or RT_MODE_DIRECT) into a film of their own, returned un-normalised in
+ * rgb[width*height*3]; the renderer's film and SPP are untouched. */
+int rt_render_aov(rt_renderer* r, int mode, int spp, uint64_t seed, uint64_t first_sample, float* rgb);
 int rt_film_clear(rt_renderer* r);                                        /* RayTracer::clear (Renderer.h:107) */
 int rt_film_spp(const rt_renderer* r);                                    /* RayTracer::getSPP (Renderer.h:652) */
 /* Un-normalised accumulation film (Film::film, Imaging.h:219) + SPP; rgb = width*height*3 floats. */

@@ -1118,6 +1118,7 @@ struct rt_renderer {
     float* film_own = nullptr;
     float* film = nullptr;
     uint8_t* tonemap_buf = nullptr;   // rt_film_tonemap's device-side image, made on first use
+    float* aov_film = nullptr;        // rt_render_aov's film, made on first use
     int spp = 0;
     DFilter filter{};   // kind 0 (BoxFilter) until rt_renderer_set_filter
     // rt_render requests not yet enqueued (see rt_render): consecutive sample ranges of one mode and seed
@@ -1506,6 +1507,28 @@ extern "C" int rt_render(rt_renderer* r, int mode, int spp, uint64_t seed, uint6
     if (!p.active) { p.active = true; p.mode = mode; p.spp = 0; p.seed = seed; p.first = first_sample; }
     p.spp += spp;
     if ((uint32_t)p.spp >= full) return flush_pending(r);
+    return RT_OK;
+}
+
+// albedoFilm / normalFilm (Renderer.h:100-103): the films getTileFilms (Renderer.h:577-603) fills for a denoiser next to the
+// beauty film.  Renders `spp` samples of an AOV / direct pass into a film of its own and hands it back un-normalised; the
+// renderer's film and SPP are not touched.
+extern "C" int rt_render_aov(rt_renderer* r, int mode, int spp, uint64_t seed, uint64_t first_sample, float* rgb) {
+    if (!r || !rgb || spp < 1) { rt_set_error("rt_render_aov: bad argument"); return RT_ERR_INVALID; }
+    if (mode != RT_MODE_AOV_ALBEDO && mode != RT_MODE_AOV_NORMAL && mode != RT_MODE_DIRECT) { rt_set_error("rt_render_aov: mode must be an AOV or the direct pass"); return RT_ERR_INVALID; }
+    if (!r->scene) { rt_set_error("rt_render_aov: the renderer's scene has been destroyed"); return RT_ERR_INVALID; }
+    { int frc_ = flush_pending(r); if (frc_) return frc_; }
+    RT_HIP(sync_all(r));
+    const size_t n = (size_t)r->W * r->H * 3;
+    if (!r->aov_film) { int rc = dev_alloc(r, &r->aov_film, n); if (rc) return rc; }
+    RT_HIP(hipMemsetAsync(r->aov_film, 0, n * sizeof(float), r->stream));
+    float* keep = r->film;
+    r->film = r->aov_film;
+    int rc = render_now(r, mode, spp, seed, first_sample);
+    r->film = keep;
+    if (rc) return rc;
+    RT_HIP(sync_all(r));
+    RT_HIP(hipMemcpy(rgb, r->aov_film, n * sizeof(float), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -178,6 +178,12 @@ public:
     void clear() { check(rt_film_clear(handle), "RayTracer::clear"); }
     // film->init(w, h, new BoxFilter()) (Renderer.h:61) with another ImageFilter: RT_FILTER_BOX / _GAUSSIAN / _MITCHELL (Imaging.h:138-214)
     void setFilter(int filter) { check(rt_renderer_set_filter(handle, filter), "RayTracer::setFilter"); }
+    // albedoFilm / normalFilm as getTileFilms fills them (Renderer.h:577-603): one AOV sample per pixel each, films of their own
+    void getAOVFilms(std::vector<float>& albedo, std::vector<float>& normal) {
+        albedo.assign((size_t)scene->camera.width * (size_t)scene->camera.height * 3, 0.0f); normal.assign(albedo.size(), 0.0f);
+        check(rt_render_aov(handle, RT_MODE_AOV_ALBEDO, 1, seed, 0, albedo.data()), "RayTracer::getAOVFilms");
+        check(rt_render_aov(handle, RT_MODE_AOV_NORMAL, 1, seed, 0, normal.data()), "RayTracer::getAOVFilms");
+    }
     void traceVPLs(int N) { check(rt_vpl_trace(handle, N, seed), "RayTracer::traceVPLs"); }   // Renderer.h:772
     void render() {
         if (type == 3) throw std::runtime_error("RayTracer::render: type 3 (OIDN denoise) is outside the hot path");

@@ -292,6 +292,24 @@ def test_aov_and_direct_passes(mode):
         assert bad.mean() < 1e-3  # a pixel can differ only where a hit flips on an edge
 
 
+def test_aov_films_of_their_own():
+    """albedoFilm / normalFilm (Renderer.h:100-103, :577-603): rt_render_aov fills a separate film and leaves the beauty film alone."""
+    s = scenes.interior("bathroom", 0.1, 96, 54)
+    sc = api.Scene(s); rt = api.RayTracer(sc)
+    rt.render(api.PATH, 3, 2, 0)
+    beauty, n = rt.film()
+    alb = rt.renderAOV(api.AOV_ALBEDO, 1, 2, 0)
+    nrm = rt.renderAOV(api.AOV_NORMAL, 2, 2, 0)
+    again, n2 = rt.film()
+    assert n2 == n == 3 and np.array_equal(again, beauty)
+    ref = api.RayTracer(sc); ref.render(api.AOV_ALBEDO, 1, 2, 0); want_a = ref.film()[0]; ref.clear()
+    ref.render(api.AOV_NORMAL, 2, 2, 0); want_n = ref.film()[0]; ref.close()
+    assert np.array_equal(alb, want_a) and np.array_equal(nrm, want_n) and alb.max() > 0 and np.abs(nrm).max() > 0
+    with pytest.raises(api.RtError):
+        rt.renderAOV(api.PATH, 1, 2, 0)
+    rt.close(); sc.close()
+
+
 def test_light_tracing_same_seed():
     s = scenes.cornell(96, 96)
     want, st = orc.OracleScene(s).render(1, 8, seed=5, threads=8)
