@@ -48,10 +48,18 @@ def main():
 
     from raytracer_amd import api, scenes
 
+    # RT_BENCH_REHEARSE=1: the N>1 control flow on a one-GPU box (every rank on GPU 0, gloo instead of RCCL); its
+    # numbers mean nothing, tests/test_two_ranks_gpu.py uses it to check that the line comes out and adds up
+    rehearse = os.environ.get("RT_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     if api.lib().rt_device_set(local_rank) != 0:
         raise SystemExit("rt_device_set failed: " + api.lib().rt_last_error().decode())
@@ -157,7 +165,8 @@ def main():
                 "workload": f"{sdata.name} procedural stand-in, {info['n_tris']} triangles, {W}x{H}, path tracing (RT_MODE_PATH), "
                             f"1 spp per step, {K} spp per rank",
                 "triangles": info["n_tris"], "width": W, "height": H, "spp_per_rank": K,
-                "parallelism": f"sample-partition x{world}" + (", RCCL film all-reduce" if world > 1 else "") + ", 2 streams per GPU",
+                "parallelism": f"sample-partition x{world}" + (", RCCL film all-reduce" if world > 1 else "") + ", 2 streams per GPU"
+                               + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearse else ""),
                 "rays_per_pixel_sample": rays / (W * H * K),
                 "film_mean": film_mean, "film_median": film_median, "film_nonfinite_values": film_nan,
             },

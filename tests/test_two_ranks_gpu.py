@@ -1,0 +1,85 @@
+"""GPU, two ranks on the one GPU of the test box, gloo in place of RCCL: raytracer_amd.dist.render_distributed
+partitions the global sample indices, each rank renders its range into its own film, and the all-reduced film must be exactly
+the sum of the two ranges' films rendered by one process (a + b in fp32 is the same either way round).  bench.py's N>1 control
+flow is rehearsed the same way (RT_BENCH_REHEARSE=1)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from raytracer_amd import api, scenes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, TOTAL, SEED = 96, 54, 5, 3
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _scene():
+    return scenes.interior("bathroom", 0.1, W, H)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import dist as rdist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert api.lib().rt_device_set(0) == 0
+    sc = api.Scene(_scene()); rt = api.RayTracer(sc)
+    film = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    spp = rdist.render_distributed(rt, api.PATH, TOTAL, SEED, film)
+    if rank == 0:
+        out.put((film.cpu().numpy().copy(), spp, rt.getSPP()))
+    dist.barrier()
+    rt.close(); sc.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_sum_to_the_films_of_their_sample_ranges():
+    from raytracer_amd import dist as rdist
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    film, spp, film_spp = out.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert spp == TOTAL and film_spp == TOTAL
+    sc = api.Scene(_scene())
+    parts = []
+    for r in range(2):
+        first, count = rdist.sample_range(TOTAL, r, 2)
+        rt = api.RayTracer(sc); rt.render(api.PATH, count, SEED, first); parts.append(rt.film()[0].reshape(-1)); rt.close()
+    sc.close()
+    assert np.array_equal(film.view(np.uint32), (parts[0] + parts[1]).view(np.uint32))
+
+
+def test_bench_line_with_two_ranks():
+    env = dict(os.environ, RT_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--detail", "0.1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 alone prints
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["steps"] == 2 and b["scaling"] == "weak" and b["value"] > 0
+    assert "cpu_baseline" not in b                           # N=1 only
+    # both ranks' rays are in the total: about twice what one rank's counters (config.rays_per_pixel_sample) hold
+    per_rank = b["config"]["rays_per_pixel_sample"] * 1920 * 1080 * 2
+    total = b["value"] * 1e6 * b["ms_per_step"] * 1e-3 * 2
+    assert 1.9 < total / per_rank < 2.1
