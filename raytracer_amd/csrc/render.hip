@@ -1442,6 +1442,7 @@ static int render_now(rt_renderer* r, int mode, int spp, uint64_t seed, uint64_t
         int rc = ensure_other_lane(r);
         if (rc) return rc;
         uint32_t nb = std::max<uint32_t>(2u, ((uint32_t)spp + bmax - 1) / bmax);
+        nb += nb & 1u;   // the same number of batches on either lane (48 spp: 4 x 12 measured 2 % faster than 3 x 16)
         // lane 1 starts behind whatever lane 0 already holds (a film clear, an earlier render): its splats are atomics on the
         // same film and would otherwise be free to land before a memset queued ahead of this render
         RT_HIP(hipEventRecord(r->acc_event, r->stream));
