@@ -15,7 +15,7 @@ from raytracer_amd.abi import Background, Camera, HIT_DTYPE, Marshalled, Materia
 from raytracer_amd.scenes import SceneData
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ORACLE_SO = os.path.join(_HERE, "liboracle.so")
+ORACLE_SO = os.environ.get("ORC_SO") or os.path.join(_HERE, "liboracle.so")   # ORC_SO: another build of rt_oracle.c (tools/bench_cpu_flags.py)
 REF_SO = os.path.join(_HERE, "_ref", "libref_geom.so")
 
 
