@@ -43,6 +43,24 @@ def test_against_oracle(make):
     sc.close()
 
 
+def test_cornell_fixed_ray_set_of_the_survey():
+    """SURVEY.md 8(d), BASELINE config 2: Cornell box at 1024x1024, 2^20 primary rays + 2^20 cosine-bounce rays + 2^20 NEE
+    segments from seed 1, every one bit-exact (the compiled reference answers when its build travelled with the tree)."""
+    s = scenes.cornell(1024, 1024)
+    ref = orc.RefScene(s) if orc.have_ref() else orc.OracleScene(s)
+    sc = api.Scene(s)
+    n = 1 << 20
+    rays = np.concatenate([scenes.primary_rays(s, n, 1), scenes.bounce_rays(s, n, 1)])
+    want = ref.traverse(rays)
+    assert_hits_bitexact(sc.traverse(rays, 0), want, "cornell 2^21 rays, wide")
+    assert_hits_bitexact(sc.traverse(rays, 1), want, "cornell 2^21 rays, reference order")
+    segs = scenes.shadow_segments(s, n, 1)
+    vis = ref.visible(segs)
+    assert np.array_equal(sc.visible(segs, 0), vis) and np.array_equal(sc.visible(segs, 1), vis)
+    assert 0 < int(vis.sum()) < n
+    sc.close()
+
+
 def test_primary_rays_from_device_camera_match_oracle():
     s = scenes.cornell(512, 512)
     o, sc = orc.OracleScene(s), api.Scene(s)
