@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--detail", type=float, default=1.0, help="scene tessellation (1.0 = ~1.1 M triangles)")
     ap.add_argument("--scene", default="bathroom")
+    ap.add_argument("--conductor", action="store_true", help="SURVEY 8(d)'s conductor variant of the scene (reported separately)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=8)
     a = ap.parse_args()
@@ -65,7 +66,7 @@ def main():
         raise SystemExit("rt_device_set failed: " + api.lib().rt_last_error().decode())
 
     W, H = 1920, 1080
-    sdata = scenes.interior(a.scene, a.detail, W, H, seed=1)
+    sdata = scenes.interior(a.scene, a.detail, W, H, seed=1, conductor=a.conductor)
     scene = api.Scene(sdata)
     info = scene.info()
     rt = api.RayTracer(scene)
@@ -162,7 +163,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{sdata.name} procedural stand-in, {info['n_tris']} triangles, {W}x{H}, path tracing (RT_MODE_PATH), "
+                "workload": f"{sdata.name} procedural stand-in{' (conductor variant)' if a.conductor else ''}, {info['n_tris']} triangles, {W}x{H}, path tracing (RT_MODE_PATH), "
                             f"1 spp per step, {K} spp per rank",
                 "triangles": info["n_tris"], "width": W, "height": H, "spp_per_rank": K,
                 "parallelism": f"sample-partition x{world}" + (", RCCL film all-reduce" if world > 1 else "") + ", 2 streams per GPU"
