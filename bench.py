@@ -142,13 +142,18 @@ def main():
         # dominant kernel = k_extend; its rays over the timed region = closest_rays
         ext_bytes = cnt["closest_rays"] * bytes_per_ray
         achieved = ext_bytes / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
-        traffic = None
+        traffic, limiter = None, None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("k_extend_hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic = pj.get("k_extend_hbm_bytes_per_launch")
+                # what the PMC passes of the same command say bounds the kernel (committed numbers, not measured by this run)
+                limiter = {k: pj.get("k_extend_" + k) for k in ("valu_busy_frac", "ta_busy_frac", "salu_busy_frac", "l2_hit_rate",
+                                                                "live_lanes_per_valu_inst", "wait_inst_frac_of_wave_cycles")}
+                limiter["source"] = "profiles/r01_pmc.json"
             except Exception:
-                traffic = None
+                traffic, limiter = None, None
         out = {
             "metric": "Mrays/s (closest + any-hit rays issued / wall time of render); ms_per_step = ms per spp, bathroom-class 1080p",
             "value": rays_all / dt_max / 1e6,
@@ -179,6 +184,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "pmc": limiter,
                 "bytes_per_ray": bytes_per_ray,
                 "nodes_per_ray": nodes_per_ray,
                 "tris_per_ray": tris_per_ray,
