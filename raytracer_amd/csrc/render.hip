@@ -46,6 +46,7 @@ struct RBuf {  // device buffers of one renderer
     float4* vpl;         // 4 * vpl_cap
     uint32_t cap, vpl_slots;
     uint32_t np_pad, tiles_x, w, h;
+    uint32_t q0, nq;   // pixel slots [q0, q0 + nq) of every sample are this launch sequence's (the whole frame: 0, np_pad)
 };
 
 __device__ __forceinline__ unsigned long long fetch_chunk(unsigned long long* work) {
@@ -204,7 +205,7 @@ __global__ void k_ctl_final(Ctl* ctl) {
 // pathTrace(px, py, sampler) (Renderer.h:203): jitter in [0,1) added to px = x + 0.5 (Renderer.h:527, :205)
 __global__ __launch_bounds__(256) void k_generate(DScene S, RBuf R, uint32_t n, uint64_t seed, uint64_t first_sample) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        uint32_t s = i / R.np_pad, q = i - s * R.np_pad;
+        uint32_t s = i / R.nq, q = R.q0 + (i - s * R.nq);
         uint32_t x, y;
         if (!slot_pixel(R, q, x, y)) { R.thr[i] = make_float4(0, 0, 0, __uint_as_float(RT_FLAG_DEAD)); continue; }
         Rng rng; rng.key = rt_rng_key(seed, first_sample + s, y * R.w + x, 0); rng.ctr = 0;
@@ -604,13 +605,13 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_connect_camera(DSce
 // ------------------------------------------------------------------------------------------------ accumulate
 // film->splat(px, py, col) with the size-0 box filter: film[(int)py * W + (int)px] += col (Imaging.h:224, Renderer.h:535)
 __global__ __launch_bounds__(256) void k_accumulate(RBuf R, float* film, uint32_t batch) {
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < R.np_pad; q += gridDim.x * blockDim.x) {
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < R.nq; q += gridDim.x * blockDim.x) {
         uint32_t x, y;
-        if (!slot_pixel(R, q, x, y)) continue;
+        if (!slot_pixel(R, R.q0 + q, x, y)) continue;
         float* f = film + ((size_t)y * R.w + x) * 3;
         float r = f[0], g = f[1], b = f[2];
         for (uint32_t s = 0; s < batch; s++) {
-            float4 L = R.rad[(size_t)s * R.np_pad + q];
+            float4 L = R.rad[(size_t)s * R.nq + q];
             r = r + L.x; g = g + L.y; b = b + L.z;
         }
         f[0] = r; f[1] = g; f[2] = b;
@@ -1275,12 +1276,19 @@ extern "C" int rt_renderer_create(rt_scene* scene, rt_renderer** out) {
     R.tiles_x = (R.w + 7) / 8;
     uint32_t tiles_y = (R.h + 7) / 8;
     R.np_pad = R.tiles_x * tiles_y * 64;
+    R.q0 = 0; R.nq = R.np_pad;
     // batch: as many samples per pixel as fit ~32 M paths per lane (about 5.3 GB of wavefront state each; the card has 288 GB)
 #ifndef RT_BATCH_PATHS
 #define RT_BATCH_PATHS (32u << 20)
 #endif
 #ifndef RT_LANES
 #define RT_LANES 2
+#endif
+#ifndef RT_SPLIT_FRAME
+#define RT_SPLIT_FRAME 1   // a one-sample render() is cut into bands of the frame that alternate between the lanes (render_now)
+#endif
+#ifndef RT_SPLIT_FRAME_PARTS
+#define RT_SPLIT_FRAME_PARTS 2
 #endif
     r->batch_max = std::max<uint32_t>(1, std::min<uint32_t>(64, RT_BATCH_PATHS / R.np_pad));
     R.cap = std::max<uint32_t>(R.np_pad * r->batch_max, (RT_MLT_PATHS + 63u) / 64u * 64u);  // room for at least one PSSMLT chain
@@ -1339,12 +1347,15 @@ static int render_path_like(rt_renderer* r, int mode, uint32_t batch, uint64_t s
     const DScene& S = r->scene->d;
     RBuf& R = r->R;
     const bool radiosity = mode == RT_MODE_RADIOSITY && r->n_vpl > 0;
-    const uint32_t n = R.np_pad * batch;
+    const uint32_t n = R.nq * batch;
+    // pixels among the slots [q0, q0 + nq): whole tile rows of 8 scanlines (render_now's split of a one-sample frame)
+    const uint32_t row0 = R.q0 / (R.tiles_x * 64u) * 8u, row1 = std::min<uint32_t>(R.h, (R.q0 + R.nq) / (R.tiles_x * 64u) * 8u);
+    const uint32_t live = (row1 > row0 ? row1 - row0 : 0u) * R.w * batch;
     LAUNCHK(RT_KID_GENERATE, k_generate, r->flat_blocks, 256, S, R, n, seed, first_sample);
     const int bounces = RT_MAX_DEPTH + 2;  // depth 0..5: the `depth > MAX_DEPTH` test sits after NEE (Renderer.h:233)
     for (int b = 0; b < bounces; b++) {
         int cur = b & 1;
-        LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n, (uint32_t)r->W * r->H * batch);
+        LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n, live);
         if (r->count_enabled) LAUNCHK(RT_KID_EXTEND, (k_extend<false, true>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
         else LAUNCHK(RT_KID_EXTEND, (k_extend<false, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
         LAUNCH(k_bin, r->flat_blocks / 2, RT_BIN_BLOCK, R, r->ctl, cur, b == 0 ? 1 : 0);
@@ -1436,6 +1447,32 @@ static int render_now(rt_renderer* r, int mode, int spp, uint64_t seed, uint64_t
     r->count_enabled = r->scene->count_enabled;  // node/triangle fetch counting (atomics) follows rt_counters_enable
     const uint32_t bmax = batch_limit(r, mode);
     int done = 0;
+    const uint32_t tile_rows = r->R.np_pad / (r->R.tiles_x * 64u);
+    if (mode == RT_MODE_PATH && spp == 1 && RT_LANES > 1 && RT_SPLIT_FRAME && !r->filter.kind && tile_rows >= 2 && r->active_lane == 0) {
+        // One sample of the frame (upstream's render() per displayed frame, Main.cpp:79-137): the upper and the lower tile rows
+        // go to the two lanes, so that the end of one half's launches overlaps the other half's work as batches do above.
+        // Every pixel gets the same film += L either way; the filtered films gather across the cut and stay on one lane.
+        int rc = ensure_other_lane(r);
+        if (rc) return rc;
+        RT_HIP(hipEventRecord(r->acc_event, r->stream));
+        RT_HIP(hipStreamWaitEvent(r->other.stream, r->acc_event, 0));
+        const uint32_t parts = std::min<uint32_t>(RT_SPLIT_FRAME_PARTS, tile_rows), row_slots = r->R.tiles_x * 64u;
+        for (uint32_t p = 0; p < parts; p++) {
+            const uint32_t a = (uint32_t)((uint64_t)tile_rows * p / parts) * row_slots, b = (uint32_t)((uint64_t)tile_rows * (p + 1) / parts) * row_slots;
+            use_lane(r, (int)(p & 1u));
+            r->R.q0 = a; r->R.nq = b - a;
+            rc = render_path_like(r, mode, 1, seed, first_sample);
+            r->R.q0 = 0; r->R.nq = r->R.np_pad;
+            if (rc) { use_lane(r, 0); return rc; }
+        }
+        use_lane(r, 1);
+        hipError_t e1 = hipEventRecord(r->acc_event, r->stream);   // lane 1
+        use_lane(r, 0);
+        RT_HIP(e1);
+        RT_HIP(hipStreamWaitEvent(r->stream, r->acc_event, 0));
+        r->acc_pending = true;
+        return RT_OK;
+    }
     if ((mode == RT_MODE_PATH || mode == RT_MODE_LIGHT) && spp >= 2 && RT_LANES > 1) {
         // at least two batches, alternating between the two lanes (streams).  Path tracing chains its film accumulation by
         // an event (fixed fp32 sum order); the light tracer's splats are atomics and need no order (PSSMLT on two lanes measured no faster).

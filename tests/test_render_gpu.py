@@ -292,6 +292,25 @@ def test_aov_and_direct_passes(mode):
         assert bad.mean() < 1e-3  # a pixel can differ only where a hit flips on an edge
 
 
+@pytest.mark.parametrize("size", [(96, 54), (64, 8), (333, 211)])
+def test_one_sample_frames_split_over_the_lanes_stay_exact(size):
+    """A render() of one sample that is looked at before the next one (upstream's displayed frame) is cut into an upper and a
+    lower half on the two streams: the film must be the one a single 5-spp call gives, bit for bit, counters included
+    (64 x 8 is one tile row: nothing to cut)."""
+    s = scenes.interior("bathroom", 0.1, *size)
+    sc = api.Scene(s)
+    a, b = api.RayTracer(sc), api.RayTracer(sc)
+    for k in range(5):
+        a.render(api.PATH, 1, 9, k)
+        a.sync()
+    b.render(api.PATH, 5, 9, 0)
+    fa, na = a.film(); fb, nb = b.film()
+    assert na == nb == 5 and np.array_equal(fa.view(np.uint32), fb.view(np.uint32))
+    ca, cb = a.counters(), b.counters()
+    assert ca["closest_rays"] == cb["closest_rays"] and ca["any_rays"] == cb["any_rays"]
+    a.close(); b.close(); sc.close()
+
+
 def test_aov_films_of_their_own():
     """albedoFilm / normalFilm (Renderer.h:100-103, :577-603): rt_render_aov fills a separate film and leaves the beauty film alone."""
     s = scenes.interior("bathroom", 0.1, 96, 54)
