@@ -6,6 +6,7 @@
 // -keys WSADEQ... (scripted key presses of Main.cpp:87-116, one per frame: move the fly camera and clear the film),
 // -dump file.rtsc (load the scene, write it as a flat file and stop: checks the loaders without a GPU).
 #include <chrono>
+#include <fstream>
 #include <iostream>
 #include <unordered_map>
 
@@ -16,7 +17,7 @@ int main(int argc, char* argv[]) {
     std::string filename = "radiosity.hdr";   // upstream's default name (Main.cpp:29)
     unsigned int SPP = 8192;
     int type = 0, width = 1024, height = 1024, perCall = 1, vpls = 0, png = 0, filter = RT_FILTER_BOX;
-    std::string dump, keys;
+    std::string dump, keys, aov;
     unsigned long long seed = 1;
     std::unordered_map<std::string, std::string> args;
     for (int i = 1; i < argc; ++i) {
@@ -46,6 +47,7 @@ int main(int argc, char* argv[]) {
             }
             else if (pair.first == "-png") png = std::stoi(pair.second);
             else if (pair.first == "-dump") dump = pair.second;
+            else if (pair.first == "-aov") aov = pair.second;
             else std::cerr << "Warning: unknown argument '" << pair.first << "'\n";
         }
         if (perCall < 1) perCall = 1;
@@ -87,6 +89,16 @@ int main(int argc, char* argv[]) {
             rt.render();
             rt.sync();
             std::cout << std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count() << std::endl;   // Main.cpp:122
+        }
+        if (!aov.empty()) {   // what getTileFilms hands the denoiser (Renderer.h:577-603): raw fp32 RGB, <prefix>.albedo.f32 / .normal.f32
+            std::vector<float> albedo, normal;
+            rt.getAOVFilms(albedo, normal);
+            for (int k = 0; k < 2; k++) {
+                std::ofstream f(aov + (k ? ".normal.f32" : ".albedo.f32"), std::ios::binary);
+                const std::vector<float>& v = k ? normal : albedo;
+                f.write(reinterpret_cast<const char*>(v.data()), (std::streamsize)(v.size() * sizeof(float)));
+                if (!f) throw std::runtime_error("-aov: cannot write " + aov);
+            }
         }
         rt.saveHDR(filename);   // Main.cpp:133-136
         if (png) {

@@ -105,6 +105,28 @@ def test_cli_fly_camera_moves_the_render(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_aov_films(tmp_path):
+    """-aov: RayTracer::getAOVFilms (albedoFilm / normalFilm of getTileFilms, Renderer.h:577-603) through the C++ host equals
+    the AOV modes rendered through the Python host, and the beauty render beside it is not disturbed."""
+    s = scenes.cornell(64, 48)
+    abi.save_rtsc(s, str(tmp_path / "scene.rtsc"))
+    outs = []
+    for extra in ([], ["-aov", str(tmp_path / "a")]):
+        out = tmp_path / f"o{len(extra)}.hdr"
+        r = subprocess.run([_cli(), "-scene", str(tmp_path), "-SPP", "4", "-sppPerCall", "4", "-seed", "9", "-outputFilename", str(out)] + extra,
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1]
+    sc = api.Scene(s); rt = api.RayTracer(sc)
+    for mode, name in ((api.AOV_ALBEDO, "albedo"), (api.AOV_NORMAL, "normal")):
+        want = rt.renderAOV(mode, 1, 9, 0)
+        got = np.fromfile(str(tmp_path / f"a.{name}.f32"), np.float32).reshape(want.shape)
+        assert np.array_equal(got, want) and np.abs(want).max() > 0
+    rt.close(); sc.close()
+
+
+@pytest.mark.gpu
 def test_cli_matches_python_host(tmp_path):
     s = scenes.cornell(64, 48)
     abi.save_rtsc(s, str(tmp_path / "scene.rtsc"))
