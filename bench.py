@@ -28,7 +28,7 @@ EXTEND_FIXED_BYTES = 72
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--detail", type=float, default=1.0, help="scene tessellation (1.0 = ~1.1 M triangles)")
     ap.add_argument("--scene", default="bathroom")
