@@ -1073,7 +1073,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_gather(DScene S, RB
     RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
     const uint32_t n = ctl->n_gather;
     if (n == 0) return;
-    const uint32_t items = n * nv;   // the host keeps cap * nv below 2^31
+    const uint32_t items = n * nv;   // the host keeps paths * nv below 2^31
     uint32_t cn = 0, ct = 0, cx = 0;
     GatherJob job{S, R, n, v0, 0ULL};
     XcdSource src; src.xf.init(items); src.w = ctl->work_x[2]; src.n = items;
@@ -1365,7 +1365,7 @@ static int render_path_like(rt_renderer* r, int mode, uint32_t batch, uint64_t s
         if (r->count_enabled) LAUNCHK(RT_KID_CONNECT, k_connect<true>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
         else LAUNCHK(RT_KID_CONNECT, k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
         if (radiosity) {
-            const uint32_t per = std::max<uint32_t>(1u, (1u << 31) / R.cap);   // item indices are 32-bit: requests x VPLs per launch < 2^31
+            const uint32_t per = std::max<uint32_t>(1u, (1u << 31) / std::max<uint32_t>(n, 1u));   // item indices are 32-bit: requests (<= n paths) x VPLs per launch < 2^31
             for (uint32_t v0 = 0; v0 < R.vpl_slots; v0 += per) {
                 if (v0) RT_HIP(hipMemsetAsync(&r->ctl->work_x[2], 0, sizeof(r->ctl->work_x[2]), r->stream));
                 LAUNCHK(RT_KID_GATHER, k_gather, r->trav_blocks, RT_BLOCK, S, R, r->ctl, v0, std::min<uint32_t>(per, R.vpl_slots - v0), r->spill4, r->spill2, r->counters);
