@@ -48,4 +48,5 @@ def derive(kname, tag):
 
 derive("k_extend<false, false>", "k_extend")
 derive("k_connect<false>", "k_connect")
+derive("k_shade<false>", "k_shade")
 print(json.dumps(res, indent=1))
