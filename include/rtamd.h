@@ -10,7 +10,8 @@
  * with rt_last_error() (the reference itself only prints / exit(0)s).  Host
  * buffers passed in are copied; the caller keeps ownership.  A scene's
  * geometry is immutable after creation and may be traversed (rt_intersect_*)
- * from several host threads; a renderer must be driven from one thread at a
+ * from several host threads and on several streams (launches that share the
+ * scene's traversal scratch are chained on the device); a renderer must be driven from one thread at a
  * time (RayTracer::render is called serially from main, Main.cpp:119), and
  * rt_scene_set_camera / rt_counters_enable / creating or destroying a
  * renderer of a scene must not overlap calls on that scene's renderers.  All device memory is owned by the

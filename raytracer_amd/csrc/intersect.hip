@@ -225,6 +225,7 @@ extern "C" int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_
 extern "C" void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     if (s->before_destroy) s->before_destroy(s);
+    if (s->scratch_event) { (void)hipEventSynchronize(s->scratch_event); (void)hipEventDestroy(s->scratch_event); }
     for (void* p : s->allocs) (void)hipFree(p);
     delete s;
 }
@@ -294,12 +295,29 @@ static int check_mode(int mode) {
     return RT_ERR_INVALID;
 }
 
+// The work counter and the two stack-spill arrays are one set per scene, and the kernels that use them run after the
+// host lock is gone: two launches on different streams (two caller streams, or two host threads in host_batch's chunked
+// path, each with a run stream of its own) would overlap on the device, reset each other's counter and push into the same
+// spill slots.  Launches that share the scratch are therefore chained on the device: each waits for the event the
+// previous one recorded behind its kernel.  Both helpers are called with s->mu held.
+static int scratch_acquire(rt_scene* s, hipStream_t st) {
+    if (!s->scratch_event) RT_HIP(hipEventCreateWithFlags(&s->scratch_event, hipEventDisableTiming));
+    if (s->scratch_busy) RT_HIP(hipStreamWaitEvent(st, s->scratch_event, 0));
+    return RT_OK;
+}
+static int scratch_release(rt_scene* s, hipStream_t st) {
+    RT_HIP(hipEventRecord(s->scratch_event, st));
+    s->scratch_busy = true;
+    return RT_OK;
+}
+
 extern "C" int rt_intersect_closest_dev(rt_scene* s, const rt_ray* d_rays, size_t n, rt_hit* d_out, int mode, void* stream) {
     if (!s || (n && (!d_rays || !d_out))) { rt_set_error("rt_intersect_closest_dev: NULL argument"); return RT_ERR_INVALID; }
     if (check_mode(mode)) return RT_ERR_INVALID;
     if (n == 0) return RT_OK;
     hipStream_t st = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(s->mu);  // the work counter and the stack spill are per scene
+    { int rc = scratch_acquire(s, st); if (rc) return rc; }
     for (size_t off = 0; off < n; off += RT_LAUNCH_MAX) {
         const uint32_t m = (uint32_t)std::min<size_t>(n - off, RT_LAUNCH_MAX);
         const float* in = (const float*)(d_rays + off);
@@ -313,7 +331,7 @@ extern "C" int rt_intersect_closest_dev(rt_scene* s, const rt_ray* d_rays, size_
                                s->d_spill4, s->d_spill2, s->d_counters);
         RT_HIP(hipGetLastError());
     }
-    return RT_OK;
+    return scratch_release(s, st);
 }
 
 extern "C" int rt_intersect_any_dev(rt_scene* s, const rt_segment* d_segs, size_t n, uint8_t* d_out, int mode, void* stream) {
@@ -322,6 +340,7 @@ extern "C" int rt_intersect_any_dev(rt_scene* s, const rt_segment* d_segs, size_
     if (n == 0) return RT_OK;
     hipStream_t st = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(s->mu);
+    { int rc = scratch_acquire(s, st); if (rc) return rc; }
     for (size_t off = 0; off < n; off += RT_LAUNCH_MAX) {
         const uint32_t m = (uint32_t)std::min<size_t>(n - off, RT_LAUNCH_MAX);
         const float* in = (const float*)(d_segs + off);
@@ -335,7 +354,7 @@ extern "C" int rt_intersect_any_dev(rt_scene* s, const rt_segment* d_segs, size_
                                s->d_spill4, s->d_spill2, s->d_counters);
         RT_HIP(hipGetLastError());
     }
-    return RT_OK;
+    return scratch_release(s, st);
 }
 
 namespace {

@@ -34,6 +34,8 @@ struct rt_scene {
     unsigned long long* d_work = nullptr;   // work-fetch counters
     uint32_t* d_spill4 = nullptr;           // overflow of the LDS stack (wide walk), may be null
     uint32_t* d_spill2 = nullptr;           // stack of the reference-order walk
+    hipEvent_t scratch_event = nullptr;     // recorded behind the last kernel that used the three arrays above (intersect.hip)
+    bool scratch_busy = false;
     int persistent_blocks = 0;
     bool count_enabled = false;
     // renderers of this scene hold rt_render requests back to merge them (render.hip): whatever changes what those

@@ -298,11 +298,17 @@ def open_box(width=96, height=96, background="env"):
     return set_camera(s, (0, 1.0, 4.4), (0, 0.8, 0), (0, 1, 0), 40.0, width, height)
 
 
-def interior(variant="bathroom", detail=1.0, width=1920, height=1080, seed=1, conductor=False):
+def interior(variant="bathroom", detail=1.0, width=1920, height=1080, seed=1, conductor=False, dielectric=False):
     """Closed-room stand-in for the bathroom / living-room scenes: ~1.0 M triangles at detail=1
     (triangle count scales ~detail^2), tessellated displaced fixtures, thin slats (blinds), glass bulbs,
     a mirror, a tiled floor with a bilinear checker texture, plastic/diffuse/glass/mirror materials and
-    four ceiling panels.  Vertices carry a <=1e-3 seeded jitter so there are no exact coplanar duplicates."""
+    four ceiling panels.  Vertices carry a <=1e-3 seeded jitter so there are no exact coplanar duplicates.
+
+    The material mix of the default scene is SURVEY 8(d)'s (diffuse / glass / mirror / plastic): every estimator in it
+    is bounded, so the film is finite and the converged-image gate can run on it.  The two unbounded upstream BSDFs are
+    opt-in variants of the same geometry, reported separately: `conductor=True` makes the small sphere of the bathroom a
+    rough conductor, `dielectric=True` a rough ("frosted") dielectric, whose half-vector draw (Materials.h:571) yields
+    inf / NaN throughputs."""
     rng = np.random.default_rng(seed + (0 if variant == "bathroom" else 1000))
     b = _Builder()
     tex = [solid((0.8, 0.8, 0.78)),                       # 0 wall paint
@@ -323,7 +329,8 @@ def interior(variant="bathroom", detail=1.0, width=1920, height=1080, seed=1, co
             Material(DIFFUSE, 4),                                       # 7
             Material(ORENNAYAR, 5, sigma=0.4),                          # 8
             Material(PLASTIC, 7, int_ior=1.4, ext_ior=1.0, roughness=0.2),    # 9 slats
-            Material(DIELECTRIC, 3, int_ior=1.33, ext_ior=1.0, roughness=0.1)]  # 10 frosted (one-sided)
+            Material(DIELECTRIC, 3, int_ior=1.33, ext_ior=1.0, roughness=0.1) if dielectric  # 10 frosted (one-sided), opt-in
+            else Material(PLASTIC, 5, int_ior=1.33, ext_ior=1.0, roughness=0.1)]                # 10 glazed blue (the default)
     if conductor:
         mats.append(Material(CONDUCTOR, 3, roughness=0.05, eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14)))  # 11
     X, Y, Z = 4.0, 3.0, 3.0
@@ -376,8 +383,8 @@ def interior(variant="bathroom", detail=1.0, width=1920, height=1080, seed=1, co
     return set_camera(s, (3.3, 1.65, 2.5), (-1.2, 0.9, -0.9), (0, 1, 0), 55.0, width, height)
 
 
-def bathroom(detail=1.0, width=1920, height=1080, seed=1):
-    return interior("bathroom", detail, width, height, seed)
+def bathroom(detail=1.0, width=1920, height=1080, seed=1, **variant):
+    return interior("bathroom", detail, width, height, seed, **variant)
 
 
 def living_room(detail=1.0, width=1920, height=1080, seed=1):

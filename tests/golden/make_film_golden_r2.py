@@ -1,0 +1,44 @@
+"""Converged reference films of the bench workloads for the image gate (round 2).
+
+bathroom-class and living-room-class stand-ins (the default, bounded material mix, detail 1.0 = the bench scene) at 240x135,
+and the diffuse Cornell box at 256x256.  The reference's Renderer.h cannot be built in this image (needs <Windows.h> / OIDN),
+so these films come from the CPU oracle (oracle/rt_oracle.c) -- "parity unpinned" as DESIGN section 5 says -- with an RNG seed
+the GPU tests do not use.  The interiors are not converged at 4096 spp (glass-to-light paths: per-pixel relative variance
+sigma^2 ~ 10, so two independent 4096-spp films are ~5e-3 apart); the reference therefore takes 32768 spp, and the GPU test
+renders enough samples for the north-star bound to be a statement about bias, not noise.
+    python tests/golden/make_film_golden_r2.py [threads]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import orc  # noqa: E402
+from raytracer_amd import scenes  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+threads = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+JOBS = (("film_cornell256_4096", lambda: scenes.cornell(256, 256), 4096),
+        ("film_bathroom240_32768", lambda: scenes.interior("bathroom", 1.0, 240, 135), 32768),
+        ("film_livingroom240_32768", lambda: scenes.interior("living-room", 1.0, 240, 135), 32768))
+for name, make, spp in JOBS:
+    out = os.path.join(HERE, name + ".npy")
+    if os.path.exists(out):
+        continue
+    s = make()
+    o = orc.OracleScene(s)
+    film = np.zeros((s.height, s.width, 3), np.float64)
+    t = time.time()
+    done = 0
+    while done < spp:   # in slices: fp32 film sums stay short, progress is visible
+        k = min(1024, spp - done)
+        part, st = o.render(mode=0, spp=k, seed=987654321, first_sample=done, threads=threads)
+        film += part
+        done += k
+        print(name, done, "%.0fs" % (time.time() - t), flush=True)
+    assert np.isfinite(film).all()
+    np.save(out, (film / spp).astype(np.float32))
+    print(name, "done", film.mean() / spp, flush=True)

@@ -5,6 +5,7 @@ import pytest
 
 import orc
 from raytracer_amd import api, scenes
+from raytracer_amd.abi import HIT_DTYPE
 from util import GOLDEN_SCENES, assert_hits_bitexact, axis_rays, load_golden
 
 pytestmark = pytest.mark.gpu
@@ -197,4 +198,39 @@ def test_full_size_wide_walk_equals_reference_order_walk(make, label):
     o = orc.OracleScene(s)
     idx = np.random.default_rng(1).integers(0, len(rays), 20_000)
     assert_hits_bitexact(a[idx], o.traverse(rays[idx], threads=16), label + " oracle slice")
+    sc.close()
+
+
+def test_launches_on_two_streams_share_the_scene_scratch_safely():
+    """rt_intersect_*_dev on two caller streams at once: the scene's work counter and stack-spill arrays are one
+    set, so the library chains such launches on the device.  Both results must be the single-call results, bit for bit."""
+    import torch
+    s = scenes.interior("bathroom", 0.3, 64, 36)
+    sc = api.Scene(s)
+    n = 3_000_000                                       # > 2 Mi items, the size ADVICE names
+    ra, rb = scenes.bounce_rays(s, n, 21), scenes.bounce_rays(s, n, 22)
+    sg = scenes.shadow_segments(s, n, 23)
+    want_a, want_b, want_v = sc.traverse(ra), sc.traverse(rb), sc.visible(sg)
+    d_a, d_b, d_s = (torch.from_numpy(x).cuda() for x in (ra, rb, sg))
+    o_a = torch.zeros(n * 5, dtype=torch.int32, device="cuda"); o_b = torch.zeros_like(o_a)
+    o_v = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    s1, s2, s3 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(2):
+        sc.traverse_dev(d_a.data_ptr(), n, o_a.data_ptr(), 0, s1.cuda_stream)
+        sc.traverse_dev(d_b.data_ptr(), n, o_b.data_ptr(), 0, s2.cuda_stream)
+        sc.visible_dev(d_s.data_ptr(), n, o_v.data_ptr(), 0, s3.cuda_stream)
+    torch.cuda.synchronize()
+    got_a, got_b = o_a.cpu().numpy().view(HIT_DTYPE), o_b.cpu().numpy().view(HIT_DTYPE)
+    assert_hits_bitexact(got_a, want_a, "stream 1")
+    assert_hits_bitexact(got_b, want_b, "stream 2")
+    assert np.array_equal(o_v.cpu().numpy(), want_v)
+    # two host threads through the host-buffer entry points (each with its own chunk pipeline and run stream)
+    import threading
+    res = {}
+    th = [threading.Thread(target=lambda k=k, r=r: res.__setitem__(k, sc.traverse(r))) for k, r in (("a", ra), ("b", rb))]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert_hits_bitexact(res["a"], want_a, "thread a")
+    assert_hits_bitexact(res["b"], want_b, "thread b")
     sc.close()
