@@ -139,6 +139,14 @@ int rt_matrix_invert(const float* m16, float* out16);
  * Host-buffer form copies in/out; the _dev form takes device pointers and a hipStream_t. */
 int rt_intersect_closest(rt_scene* scene, const rt_ray* rays, size_t n, rt_hit* out, int mode);
 int rt_intersect_closest_dev(rt_scene* scene, const rt_ray* d_rays, size_t n, rt_hit* d_out, int mode, void* stream);
+/* No counterpart in the reference: rt_intersect_closest_dev for callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same arguments and results, bit for bit; the
+ * traversal scratch (work counter + stack overflow) comes from one static device array of ~42 MB per GPU instead of the
+ * scene's own hipMalloc'ed arrays, and the call itself performs no hipMalloc / hipFree.  Limits: n <= 2^24 rays per call
+ * (RT_ERR_INVALID beyond), and a scene whose stack bounds -- (wide_max_stack - 24) + the binary tree's bound -- exceed 80
+ * words per lane is refused with RT_ERR_UNSUPPORTED.  Every call on a GPU shares that GPU's array: calls that overlap
+ * on one GPU (two streams, two host threads) race -- run them on one stream.  The scene's device must be current. */
+int rt_intersect_closest_noalloc(rt_scene* scene, const rt_ray* d_rays, size_t n, rt_hit* d_out, int mode, void* stream);
 /* --- bool Scene::visible(const Vec3&, const Vec3&) (Scene.h:169), batched; out[i] = 1 if visible. */
 int rt_intersect_any(rt_scene* scene, const rt_segment* segs, size_t n, uint8_t* out, int mode);
 int rt_intersect_any_dev(rt_scene* scene, const rt_segment* d_segs, size_t n, uint8_t* d_out, int mode, void* stream);

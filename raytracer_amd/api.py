@@ -56,7 +56,7 @@ SYMBOLS = [
     "rt_renderer_create", "rt_renderer_destroy", "rt_render", "rt_film_clear", "rt_film_spp", "rt_film_read", "rt_film_bind",
     "rt_film_set_spp", "rt_vpl_trace", "rt_vpl_count", "rt_render_counters", "rt_renderer_sync", "rt_film_save_hdr",
     "rt_film_tonemap", "rt_profile_enable", "rt_profile_read", "rt_debug_bsdf_sample", "rt_debug_bsdf_eval", "rt_debug_rng", "rt_matrix_invert", "rt_scene_create_ex",
-    "rt_renderer_set_filter", "rt_render_aov",
+    "rt_renderer_set_filter", "rt_render_aov", "rt_intersect_closest_noalloc",
 ]
 
 
@@ -92,6 +92,7 @@ def lib():
         _sig(L, "rt_host_build_info", [C.POINTER(SceneDesc), vp, C.POINTER(SceneInfo)])
         _sig(L, "rt_intersect_closest", [vp, vp, sz, vp, i32])
         _sig(L, "rt_intersect_closest_dev", [vp, vp, sz, vp, i32, vp])
+        _sig(L, "rt_intersect_closest_noalloc", [vp, vp, sz, vp, i32, vp])
         _sig(L, "rt_intersect_any", [vp, vp, sz, vp, i32])
         _sig(L, "rt_intersect_any_dev", [vp, vp, sz, vp, i32, vp])
         _sig(L, "rt_generate_rays", [vp, vp, sz, vp])
@@ -204,6 +205,9 @@ class Scene:
 
     def traverse_dev(self, d_rays_ptr, n, d_out_ptr, mode=0, stream=None):
         _check(self.L.rt_intersect_closest_dev(self.h, d_rays_ptr, n, d_out_ptr, mode, stream), "rt_intersect_closest_dev")
+
+    def traverse_noalloc(self, d_rays_ptr, n, d_out_ptr, mode=0, stream=None):
+        _check(self.L.rt_intersect_closest_noalloc(self.h, d_rays_ptr, n, d_out_ptr, mode, stream), "rt_intersect_closest_noalloc")
 
     def visible_dev(self, d_segs_ptr, n, d_out_ptr, mode=0, stream=None):
         _check(self.L.rt_intersect_any_dev(self.h, d_segs_ptr, n, d_out_ptr, mode, stream), "rt_intersect_any_dev")

@@ -161,6 +161,8 @@ int rt_scene_persistent_blocks(const rt_scene* s) { return s->persistent_blocks;
 
 bool device_bvh2_build(const float* h_verts, uint32_t n, Bvh2& out, std::string& err);   // bvh_build.hip
 
+static int na_scratch_setup(int device);   // scratch of the no-allocation entry point (below)
+
 extern "C" int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) { return rt_scene_create_ex(desc, 0u, out); }
 
 extern "C" int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_scene** out) {
@@ -180,6 +182,7 @@ extern "C" int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_
     int rc = RT_OK;
     auto fail = [&](int code) { rt_scene_destroy(s); return code; };
     if (hipGetDevice(&s->device) != hipSuccess) return fail(RT_ERR_DEVICE);
+    if ((rc = na_scratch_setup(s->device))) return fail(rc);
     HostScene& h = s->host;
     DScene& d = s->d;
     if ((rc = upload(s, h.tris, &d.tris)) || (rc = upload(s, h.trishade, &d.trishade)) || (rc = upload(s, h.nodes4, &d.nodes4)) ||
@@ -355,6 +358,65 @@ extern "C" int rt_intersect_any_dev(rt_scene* s, const rt_segment* d_segs, size_
         RT_HIP(hipGetLastError());
     }
     return scratch_release(s, st);
+}
+
+// ------------------------------------------------------------------------------------------------ no-allocation entry point
+// rt_intersect_closest_dev for callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid
+// hipMalloc).  The traversal kernel needs scratch beyond its inputs and outputs -- the work counter its waves draw ray
+// indices from and the overflow of the per-lane traversal stacks -- which the other entry points take from arrays the
+// scene allocated with hipMalloc.  Here it lives in one file-scope device array of fixed size (RT_NA_BYTES, ~42 MB per GPU
+// the library runs on, held until the process ends), so the call itself allocates nothing; the price is a fixed, smaller
+// grid (RT_NA_BLOCKS blocks), a cap on the batch (RT_NA_MAX_RAYS) and on the scene's stack bounds (RT_NA_WORDS per lane).
+// `scratch` is a host-side stand-in, not a device address: host code only ever uses the per-device pointer that
+// hipGetSymbolAddress returned for it (na_scratch_ptr), taken once per device at scene creation with that device current.
+// Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race.
+#define RT_NA_BLOCKS 512u
+#define RT_NA_THREADS (RT_NA_BLOCKS * RT_BLOCK)
+#define RT_NA_WORDS 80u                       // stack words per lane: (wide_max_stack - RT_STACK_LDS) + max(bvh2 stack bound, 2)
+#define RT_NA_HEADER 64u                      // words in front of the stacks: the work counter, in a 256-B line of its own
+#define RT_NA_MAX_RAYS ((size_t)1 << 24)
+#define RT_NA_BYTES ((size_t)(RT_NA_HEADER + (size_t)RT_NA_THREADS * RT_NA_WORDS) * sizeof(uint32_t))
+static __device__ __align__(256) uint32_t scratch[RT_NA_HEADER + (size_t)RT_NA_THREADS * RT_NA_WORDS];
+#define RT_NA_MAX_DEVICES 64
+static uint32_t* na_scratch_ptr[RT_NA_MAX_DEVICES];   // device address of `scratch` on each GPU (every GPU holds its own copy)
+static std::mutex na_mu;
+
+// once per device, with that device current (rt_scene_create_ex calls it)
+static int na_scratch_setup(int device) {
+    if (device < 0 || device >= RT_NA_MAX_DEVICES) return RT_OK;   // such a device simply has no no-allocation path
+    std::lock_guard<std::mutex> lk(na_mu);
+    if (na_scratch_ptr[device]) return RT_OK;
+    uint32_t* ptr = nullptr;
+    RT_HIP(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+    na_scratch_ptr[device] = ptr;
+    return RT_OK;
+}
+
+extern "C" int rt_intersect_closest_noalloc(rt_scene* s, const rt_ray* d_rays, size_t n, rt_hit* d_out, int mode, void* stream) {
+    if (!s || (n && (!d_rays || !d_out))) { rt_set_error("rt_intersect_closest_noalloc: NULL argument"); return RT_ERR_INVALID; }
+    if (check_mode(mode)) return RT_ERR_INVALID;
+    if (n > RT_NA_MAX_RAYS) { rt_set_error("rt_intersect_closest_noalloc: at most 2^24 rays per call (use rt_intersect_closest_dev for larger batches)"); return RT_ERR_INVALID; }
+    const uint32_t s4 = s->host.max_stack4 > RT_STACK_LDS ? (s->host.max_stack4 - RT_STACK_LDS) * (RT_STACK_KEYS ? 2u : 1u) : 0u;
+    const uint32_t s2 = std::max<uint32_t>(s->host.max_stack2, 2);
+    if (s4 + s2 > RT_NA_WORDS) {
+        rt_set_error("rt_intersect_closest_noalloc: the scene's traversal stack bounds (" + std::to_string(s4) + " + " + std::to_string(s2) +
+                     " words per lane) exceed the static scratch (" + std::to_string(RT_NA_WORDS) + "); use rt_intersect_closest_dev");
+        return RT_ERR_UNSUPPORTED;
+    }
+    uint32_t* ptr = (s->device >= 0 && s->device < RT_NA_MAX_DEVICES) ? na_scratch_ptr[s->device] : nullptr;
+    if (!ptr) { rt_set_error("rt_intersect_closest_noalloc: no static scratch on this device"); return RT_ERR_UNSUPPORTED; }
+    if (n == 0) return RT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    // the array keeps the last call's contents: the work counter must start at zero (stack slots are written before they are read)
+    RT_HIP(hipMemsetAsync(ptr, 0, sizeof(unsigned long long), st));
+    const uint32_t m = (uint32_t)n;
+    const unsigned blocks = (unsigned)std::min<size_t>(((size_t)m + RT_BLOCK - 1) / RT_BLOCK, std::min<size_t>(RT_NA_BLOCKS, (size_t)s->persistent_blocks));
+    uint32_t* spill4 = s4 ? ptr + RT_NA_HEADER : nullptr;
+    uint32_t* spill2 = ptr + RT_NA_HEADER + (size_t)RT_NA_THREADS * s4;
+    hipLaunchKernelGGL(k_intersect_closest<false>, dim3(blocks), dim3(RT_BLOCK), 0, st, s->d, (const float*)d_rays, m, d_out, mode,
+                       (unsigned long long*)ptr, spill4, spill2, s->d_counters);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
 }
 
 namespace {
