@@ -186,6 +186,10 @@ int rt_renderer_set_filter(rt_renderer* r, int filter);
  * RT_MODE_AOV_ALBEDO / RT_MODE_AOV_NORMAL (or RT_MODE_DIRECT) into a film of their own, returned un-normalised in
  * rgb[width*height*3]; the renderer's film and SPP are untouched. */
 int rt_render_aov(rt_renderer* r, int mode, int spp, uint64_t seed, uint64_t first_sample, float* rgb);
+/* How many HIP streams rt_render spreads its batches over: 2 (the default: the end of one batch's persistent kernels overlaps
+ * the other batch's work) or 1 (every kernel runs alone: the unshared per-kernel durations bench.py reports beside the shared
+ * ones).  Same film either way.  No counterpart upstream. */
+int rt_renderer_set_streams(rt_renderer* r, int n);
 int rt_film_clear(rt_renderer* r);                                        /* RayTracer::clear (Renderer.h:107) */
 int rt_film_spp(const rt_renderer* r);                                    /* RayTracer::getSPP (Renderer.h:652) */
 /* Un-normalised accumulation film (Film::film, Imaging.h:219) + SPP; rgb = width*height*3 floats. */

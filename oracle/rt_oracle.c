@@ -1025,6 +1025,16 @@ static Col vpl_contribution(Ctx* c, const Shading* sd) {
 /* Renderer.h:215-255 (radiosity == 0) and :910-962 (radiosity == 1), iterative
  * form of the tail recursion; the per-vertex terms are summed right-to-left as
  * the recursion returns them. */
+/* debugging aid of the tests: when set, path_trace logs 20 floats per path vertex (orc_trace_path) */
+static __thread float* g_trace = NULL;
+static __thread int g_trace_n = 0, g_trace_cap = 0;
+static void trace_vertex(const Shading* sd, Col T_in, Col direct, Col f, float pdf, V3 wi) {
+    if (!g_trace || g_trace_n >= g_trace_cap) return;
+    float* r = g_trace + 20 * g_trace_n++;
+    r[0] = (float)sd->mat; r[1] = T_in.r; r[2] = T_in.g; r[3] = T_in.b; r[4] = direct.r; r[5] = direct.g; r[6] = direct.b;
+    r[7] = f.r; r[8] = f.g; r[9] = f.b; r[10] = pdf; r[11] = wi.x; r[12] = wi.y; r[13] = wi.z;
+    r[14] = sd->wo.x; r[15] = sd->wo.y; r[16] = sd->wo.z; r[17] = sd->sN.x; r[18] = sd->sN.y; r[19] = sd->sN.z;
+}
 static Col path_trace(Ctx* c, V3 o, V3 dir, Rng* rng, int radiosity) {
     const orc_scene* s = c->s;
     Col T = col(1, 1, 1);
@@ -1048,6 +1058,7 @@ static Col path_trace(Ctx* c, V3 o, V3 dir, Rng* rng, int radiosity) {
         else break;
         Col f; float pdf;
         V3 wi = bsdf_sample(s, &sd, rng, &f, &pdf);
+        trace_vertex(&sd, T, direct, f, pdf, wi);
         T = cdivf(cmulf(cmul(T, f), fabsf(vdot(wi, sd.sN))), pdf);
         o = vadd(sd.x, vmulf(wi, EPSILON));
         dir = wi;
@@ -1321,6 +1332,21 @@ static void render_pixel(Job* j, int x, int y) {
         }
         film_add(j->film, W, H, px, py, L, 0, j->mode >= 10 ? 0 : s->filter); /* Renderer.h:535; the AOV films keep their BoxFilter (Renderer.h:100-103) */
     }
+}
+/* One path-tracing sample of one pixel with a per-vertex log (20 floats each: material, throughput before the vertex, NEE term,
+ * f, pdf, wi, wo, shading normal); returns the number of vertices logged and the sample's radiance in L[3]. */
+int orc_trace_path(orc_scene* s, int x, int y, uint64_t seed, uint64_t sample, float* log, int cap, float* L3) {
+    Ctx ctx; memset(&ctx, 0, sizeof(ctx)); ctx.s = s;
+    Rng rng = rng_make(seed, sample, (uint32_t)(y * (int)s->width + x), 0);
+    float px = x + 0.5f, py = y + 0.5f;
+    float u1 = rng_next(&rng), u2 = rng_next(&rng);
+    V3 o, d;
+    camera_ray(s, px + u1, py + u2, &o, &d);
+    g_trace = log; g_trace_n = 0; g_trace_cap = cap;
+    Col L = path_trace(&ctx, o, d, &rng, 0);
+    g_trace = NULL;
+    L3[0] = L.r; L3[1] = L.g; L3[2] = L.b;
+    return g_trace_n;
 }
 static void* render_worker(void* arg) {
     Job* j = (Job*)arg;

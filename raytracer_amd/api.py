@@ -56,7 +56,7 @@ SYMBOLS = [
     "rt_renderer_create", "rt_renderer_destroy", "rt_render", "rt_film_clear", "rt_film_spp", "rt_film_read", "rt_film_bind",
     "rt_film_set_spp", "rt_vpl_trace", "rt_vpl_count", "rt_render_counters", "rt_renderer_sync", "rt_film_save_hdr",
     "rt_film_tonemap", "rt_profile_enable", "rt_profile_read", "rt_debug_bsdf_sample", "rt_debug_bsdf_eval", "rt_debug_rng", "rt_matrix_invert", "rt_scene_create_ex",
-    "rt_renderer_set_filter", "rt_render_aov", "rt_intersect_closest_noalloc",
+    "rt_renderer_set_filter", "rt_render_aov", "rt_intersect_closest_noalloc", "rt_renderer_set_streams",
 ]
 
 
@@ -109,6 +109,7 @@ def lib():
         _sig(L, "rt_film_set_spp", [vp, i32])
         _sig(L, "rt_vpl_trace", [vp, i32, u64])
         _sig(L, "rt_renderer_set_filter", [vp, i32])
+        _sig(L, "rt_renderer_set_streams", [vp, i32])
         _sig(L, "rt_render_aov", [vp, i32, i32, u64, u64, vp])
         _sig(L, "rt_vpl_count", [vp])
         _sig(L, "rt_render_counters", [vp, C.POINTER(Counters), i32])
@@ -292,6 +293,9 @@ class RayTracer:
     def setFilter(self, kind):
         """film->init(w, h, new BoxFilter / GaussianFilter / MitchellNetravaliFilter) (Renderer.h:61): FILTER_BOX / _GAUSSIAN / _MITCHELL."""
         _check(self.L.rt_renderer_set_filter(self.h, kind), "rt_renderer_set_filter")
+
+    def set_streams(self, n):
+        _check(self.L.rt_renderer_set_streams(self.h, n), "rt_renderer_set_streams")
 
     def renderAOV(self, mode, spp=1, seed=1, first_sample=0):
         """albedoFilm / normalFilm of getTileFilms (Renderer.h:577-603): an AOV pass into a film of its own (un-normalised)."""

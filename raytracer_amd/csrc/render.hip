@@ -5,7 +5,7 @@
 // on one HIP stream with no host round trip: queue lengths live in a device control block that each kernel
 // reads, waves pull 64-item chunks from work counters, live paths are compacted with ballot + prefix
 // appends (one atomic per wave per queue), and hits are binned per BSDF class so a shade wave runs one
-// material's code.  Path state is SoA float4 in HBM (80 B/path), the film is a plain fp32 RGB sum.
+// material's code.  Path state is one 64-B record per path in HBM (+16 B radiance), the film is a plain fp32 RGB sum.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -37,7 +37,11 @@ struct alignas(128) Ctl {
 };
 
 struct RBuf {  // device buffers of one renderer
-    float4 *ray_o, *ray_d, *hit, *thr, *rad;
+    // path state, one 64-B record per path: [0] ray origin + rng key, [1] ray direction + rng counter, [2] hit (t, u, v, rank),
+    // [3] throughput + flags.  After the first bounce paths are reached through the queues (scattered): as four SoA arrays a
+    // shade lane touched four 64-B sectors for 64 B of state, as a record it touches one.
+    float4* st;
+    float4* rad;
     uint32_t* q_active[2];
     uint32_t* q_class;   // RT_NCLASS * cap
     uint32_t* cls;       // per path: BSDF class of the hit extend found, RT_CLS_NONE when the path ended
@@ -207,15 +211,15 @@ __global__ __launch_bounds__(256) void k_generate(DScene S, RBuf R, uint32_t n, 
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         uint32_t s = i / R.nq, q = R.q0 + (i - s * R.nq);
         uint32_t x, y;
-        if (!slot_pixel(R, q, x, y)) { R.thr[i] = make_float4(0, 0, 0, __uint_as_float(RT_FLAG_DEAD)); continue; }
+        if (!slot_pixel(R, q, x, y)) { R.st[(size_t)i * 4 + 3] = make_float4(0, 0, 0, __uint_as_float(RT_FLAG_DEAD)); continue; }
         Rng rng; rng.key = rt_rng_key(seed, first_sample + s, y * R.w + x, 0); rng.ctr = 0;
         float px = x + 0.5f, py = y + 0.5f;
         float u1 = rt_rng_next(rng), u2 = rt_rng_next(rng);
         f3 o, d;
         camera_ray(S.cam, px + u1, py + u2, o, d);
-        R.ray_o[i] = make_float4(o.x, o.y, o.z, __uint_as_float(rng.key));
-        R.ray_d[i] = make_float4(d.x, d.y, d.z, __uint_as_float(rng.ctr));
-        R.thr[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(RT_FLAG_CANHIT));
+        R.st[(size_t)i * 4 + 0] = make_float4(o.x, o.y, o.z, __uint_as_float(rng.key));
+        R.st[(size_t)i * 4 + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(rng.ctr));
+        R.st[(size_t)i * 4 + 3] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(RT_FLAG_CANHIT));
         R.rad[i] = make_float4(0, 0, 0, 0);
     }
 }
@@ -246,8 +250,8 @@ struct ExtendJob {
     __device__ __forceinline__ uint32_t path_of(uint32_t i) const { return first ? i : queue[i]; }
     __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d) {
         uint32_t path = path_of(i);
-        if (__float_as_uint(R.thr[path].w) & RT_FLAG_DEAD) { R.cls[path] = RT_CLS_NONE; return false; }
-        float4 ro = R.ray_o[path], rd = R.ray_d[path];
+        if (__float_as_uint(R.st[(size_t)path * 4 + 3].w) & RT_FLAG_DEAD) { R.cls[path] = RT_CLS_NONE; return false; }
+        float4 ro = R.st[(size_t)path * 4 + 0], rd = R.st[(size_t)path * 4 + 1];
         o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z);
         return true;
     }
@@ -259,26 +263,28 @@ struct ExtendJob {
             uint32_t mat = S.tris[h.rank].mat_gsign & 0x7FFFFFFFu;
             const DMaterial& m = S.mats[mat];
             if (!LT && (m.flags & RT_MF_LIGHT)) {
-                float4 th = R.thr[path];
+                float4 th = R.st[(size_t)path * 4 + 3];
                 if (__float_as_uint(th.w) & RT_FLAG_CANHIT) {
                     float4 L = R.rad[path];
                     col3 c = mkc(th.x, th.y, th.z) * mat_emission(m);
                     R.rad[path] = make_float4(L.x + c.r, L.y + c.g, L.z + c.b, L.w);
                 }
             } else {
-                R.hit[path] = make_float4(h.t, h.u, h.v, __uint_as_float(h.rank));
+                R.st[(size_t)path * 4 + 2] = make_float4(h.t, h.u, h.v, __uint_as_float(h.rank));
                 cls = LT ? 0u : (uint32_t)class_of(m.type);
             }
         } else if (!LT) {
             float4 L = R.rad[path];
-            float4 rd = R.ray_d[path];  // not w.dir: a zero / untamed direction never initialises the walk
+            float4 rd = R.st[(size_t)path * 4 + 1];  // not w.dir: a zero / untamed direction never initialises the walk
             col3 c = bg_evaluate(S, mk3(rd.x, rd.y, rd.z));
             R.rad[path] = make_float4(L.x + c.r, L.y + c.g, L.z + c.b, L.w);
         }
         R.cls[path] = cls;
     }
 };
-template <bool LT, bool COUNT>
+// TAG only gives the launches of a one-stream renderer (rt_renderer_set_streams) a kernel name of their own, so that a
+// profiler's per-kernel average keeps the shared (two-stream) and the unshared launch durations apart.
+template <bool LT, bool COUNT, int TAG = 0>
 __global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_extend(DScene S, RBuf R, Ctl* ctl, int cur, int first, uint32_t* spill4, uint32_t* spill2,
                                                      DCounters* counters) {
     __shared__ uint32_t lds_stack[RT_STACK_WORDS];
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_OCC) void k_shade(DScene S
 #pragma unroll
             for (int k = 0; k < RT_NCLASS - 1; k++) if (c == k && idx >= cnt[k]) { idx -= cnt[k]; c = k + 1; }
             path = R.q_class[(size_t)c * R.cap + idx];
-            float4 ro = R.ray_o[path], rd = R.ray_d[path], hh = R.hit[path], th = R.thr[path];
+            float4 ro = R.st[(size_t)path * 4 + 0], rd = R.st[(size_t)path * 4 + 1], hh = R.st[(size_t)path * 4 + 2], th = R.st[(size_t)path * 4 + 3];
             f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
             Rng rng; rng.key = __float_as_uint(ro.w); rng.ctr = __float_as_uint(rd.w);
             uint32_t flags = __float_as_uint(th.w);
@@ -423,9 +429,9 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_OCC) void k_shade(DScene S
                     f3 wi = bsdf_sample(S, sd, rng, f, pdf);
                     T = ((T * f) * fabsf(dot3(wi, sd.sN))) / pdf;
                     f3 no = sd.x + (wi * RT_EPSILON);
-                    R.ray_o[path] = make_float4(no.x, no.y, no.z, ro.w);
-                    R.ray_d[path] = make_float4(wi.x, wi.y, wi.z, __uint_as_float(rng.ctr));
-                    R.thr[path] = make_float4(T.r, T.g, T.b, __uint_as_float((depth + 1) | (specular ? RT_FLAG_CANHIT : 0u)));
+                    R.st[(size_t)path * 4 + 0] = make_float4(no.x, no.y, no.z, ro.w);
+                    R.st[(size_t)path * 4 + 1] = make_float4(wi.x, wi.y, wi.z, __uint_as_float(rng.ctr));
+                    R.st[(size_t)path * 4 + 3] = make_float4(T.r, T.g, T.b, __uint_as_float((depth + 1) | (specular ? RT_FLAG_CANHIT : 0u)));
                     want_next = true;
                 }
             }
@@ -673,9 +679,9 @@ __global__ __launch_bounds__(256) void k_mlt_generate(DScene S, RBuf R, uint32_t
         float u1 = rt_rng_next(rng), u2 = rt_rng_next(rng);
         f3 o, d;
         camera_ray(S.cam, x + u1, y + u2, o, d);    // pathTrace(px, py, sampler) (Renderer.h:203-207)
-        R.ray_o[i] = make_float4(o.x, o.y, o.z, __uint_as_float(rng.key));
-        R.ray_d[i] = make_float4(d.x, d.y, d.z, __uint_as_float(rng.ctr));
-        R.thr[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(RT_FLAG_CANHIT));
+        R.st[(size_t)i * 4 + 0] = make_float4(o.x, o.y, o.z, __uint_as_float(rng.key));
+        R.st[(size_t)i * 4 + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(rng.ctr));
+        R.st[(size_t)i * 4 + 3] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(RT_FLAG_CANHIT));
         R.rad[i] = make_float4(0, 0, 0, 0);
     }
 }
@@ -881,11 +887,11 @@ __global__ __launch_bounds__(RT_LT_BLOCK) void k_lt_generate(DScene S, RBuf R, C
             Rng rng; rng.key = rt_rng_key(seed, first_sample + s, pix, 1); rng.ctr = 0;
             light_emit(S, rng, 0.0f, false, p, wi, Le, ln, ok);
             if (ok) {
-                R.ray_o[i] = make_float4(p.x, p.y, p.z, __uint_as_float(rng.key));
-                R.ray_d[i] = make_float4(wi.x, wi.y, wi.z, __uint_as_float(rng.ctr));
-                R.thr[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(0u));
+                R.st[(size_t)i * 4 + 0] = make_float4(p.x, p.y, p.z, __uint_as_float(rng.key));
+                R.st[(size_t)i * 4 + 1] = make_float4(wi.x, wi.y, wi.z, __uint_as_float(rng.ctr));
+                R.st[(size_t)i * 4 + 3] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(0u));
                 R.rad[i] = make_float4(Le.r, Le.g, Le.b, 0);
-            } else R.thr[i] = make_float4(0, 0, 0, __uint_as_float(RT_FLAG_DEAD));
+            } else R.st[(size_t)i * 4 + 3] = make_float4(0, 0, 0, __uint_as_float(RT_FLAG_DEAD));
         }
         // connectToCamera returns before Scene::visible when the point projects outside the film (Renderer.h:672): no request
         float px_, py_;
@@ -915,7 +921,7 @@ __global__ __launch_bounds__(RT_LT_BLOCK) void k_lt_shade(DScene S, RBuf R, Ctl*
         float4 sh_a, sh_c;
         if (live) {
             path = R.q_class[g];
-            float4 ro = R.ray_o[path], rd = R.ray_d[path], hh = R.hit[path], th = R.thr[path], le4 = R.rad[path];
+            float4 ro = R.st[(size_t)path * 4 + 0], rd = R.st[(size_t)path * 4 + 1], hh = R.st[(size_t)path * 4 + 2], th = R.st[(size_t)path * 4 + 3], le4 = R.rad[path];
             f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
             Rng rng; rng.key = __float_as_uint(ro.w); rng.ctr = __float_as_uint(rd.w);
             uint32_t depth = __float_as_uint(th.w) & 0xFFu;
@@ -940,9 +946,9 @@ __global__ __launch_bounds__(RT_LT_BLOCK) void k_lt_shade(DScene S, RBuf R, Ctl*
                     col3 f = bsdf_eval(S, sd, nw);
                     T = ((T * f) * fabsf(dot3(nw, sd.sN))) / pdf;
                     f3 no = sd.x + (nw * RT_EPSILON);
-                    R.ray_o[path] = make_float4(no.x, no.y, no.z, ro.w);
-                    R.ray_d[path] = make_float4(nw.x, nw.y, nw.z, __uint_as_float(rng.ctr));
-                    R.thr[path] = make_float4(T.r, T.g, T.b, __uint_as_float(depth + 1));
+                    R.st[(size_t)path * 4 + 0] = make_float4(no.x, no.y, no.z, ro.w);
+                    R.st[(size_t)path * 4 + 1] = make_float4(nw.x, nw.y, nw.z, __uint_as_float(rng.ctr));
+                    R.st[(size_t)path * 4 + 3] = make_float4(T.r, T.g, T.b, __uint_as_float(depth + 1));
                     want_next = true;
                 }
             }
@@ -1108,6 +1114,9 @@ __global__ void k_debug_bsdf(DScene S, uint32_t mat, const float* wo, const floa
 }
 
 // ================================================================================================= host side
+#ifndef RT_LANES
+#define RT_LANES 2
+#endif
 enum { RT_KID_GENERATE = 0, RT_KID_EXTEND, RT_KID_SHADE, RT_KID_CONNECT, RT_KID_GATHER, RT_KID_ACCUMULATE, RT_KID_CTL, RT_KID_COUNT };
 struct rt_renderer {
     rt_scene* scene = nullptr;
@@ -1129,6 +1138,8 @@ struct rt_renderer {
     uint32_t* spill2 = nullptr;
     int trav_blocks = 0, flat_blocks = 0;
     int n_vpl = 0;
+    uint32_t vpl_cap = 0;             // light samples the VPL record / walk-stack buffers hold (rt_vpl_trace)
+    uint32_t* vpl_stack = nullptr;
     // Second lane: a full second set of wavefront state on its own stream.  rt_render alternates path-tracing batches
     // between the two lanes, so the tail of one batch's persistent kernels (a launch lasts as long as its slowest ray:
     // 0.6-2 ms of nearly idle GPU per k_extend launch on the bench scene) overlaps the other batch's work.  The active
@@ -1140,6 +1151,7 @@ struct rt_renderer {
     hipEvent_t acc_event = nullptr;   // film accumulation of the previous batch (keeps the fp32 sum order fixed)
     bool acc_pending = false;
     bool count_enabled = false;
+    int lanes = RT_LANES;   // 2: batches alternate between the two streams; 1: everything on one stream (rt_renderer_set_streams)
     std::vector<void*> allocs;
     // per-kernel HIP-event timing on the renderer's own stream (rt_profile_enable)
     bool profile = false;
@@ -1199,8 +1211,7 @@ extern "C" void rt_renderer_destroy(rt_renderer* r) {
 
 static int alloc_state(rt_renderer* r, RBuf& R, Ctl** ctl) {
     int rc;
-    if ((rc = dev_alloc(r, &R.ray_o, R.cap)) || (rc = dev_alloc(r, &R.ray_d, R.cap)) || (rc = dev_alloc(r, &R.hit, R.cap)) ||
-        (rc = dev_alloc(r, &R.thr, R.cap)) || (rc = dev_alloc(r, &R.rad, R.cap)) || (rc = dev_alloc(r, &R.q_active[0], R.cap)) ||
+    if ((rc = dev_alloc(r, &R.st, (size_t)R.cap * 4)) || (rc = dev_alloc(r, &R.rad, R.cap)) || (rc = dev_alloc(r, &R.q_active[0], R.cap)) ||
         (rc = dev_alloc(r, &R.q_active[1], R.cap)) || (rc = dev_alloc(r, &R.q_class, (size_t)R.cap * RT_NCLASS)) || (rc = dev_alloc(r, &R.cls, R.cap)) ||
         (rc = dev_alloc(r, &R.shadow, (size_t)R.cap * 3)) || (rc = dev_alloc(r, ctl, 1)))
         return rc;
@@ -1264,6 +1275,14 @@ extern "C" int rt_renderer_set_filter(rt_renderer* r, int kind) {
     return RT_OK;
 }
 
+extern "C" int rt_renderer_set_streams(rt_renderer* r, int n) {
+    if (!r || (n != 1 && n != 2)) { rt_set_error("rt_renderer_set_streams: 1 or 2 streams"); return RT_ERR_INVALID; }
+    { int frc_ = flush_pending(r); if (frc_) return frc_; }
+    RT_HIP(sync_all(r));
+    r->lanes = n;
+    return RT_OK;
+}
+
 extern "C" int rt_renderer_create(rt_scene* scene, rt_renderer** out) {
     if (!scene || !out) { rt_set_error("rt_renderer_create: NULL argument"); return RT_ERR_INVALID; }
     if (!scene->has_camera) { rt_set_error("rt_renderer_create: scene has no camera (rt_scene_set_camera)"); return RT_ERR_INVALID; }
@@ -1281,9 +1300,6 @@ extern "C" int rt_renderer_create(rt_scene* scene, rt_renderer** out) {
     // 32 spp per batch at 1080p measured 1.5 % faster than 16 (2492 -> 2529 Mrays/s at 64 spp per call)
 #ifndef RT_BATCH_PATHS
 #define RT_BATCH_PATHS (64u << 20)
-#endif
-#ifndef RT_LANES
-#define RT_LANES 2
 #endif
 #ifndef RT_SPLIT_FRAME
 #define RT_SPLIT_FRAME 1   // a one-sample render() is cut into bands of the frame that alternate between the lanes (render_now)
@@ -1358,6 +1374,7 @@ static int render_path_like(rt_renderer* r, int mode, uint32_t batch, uint64_t s
         int cur = b & 1;
         LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n, live);
         if (r->count_enabled) LAUNCHK(RT_KID_EXTEND, (k_extend<false, true>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
+        else if (r->lanes == 1) LAUNCHK(RT_KID_EXTEND, (k_extend<false, false, 1>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
         else LAUNCHK(RT_KID_EXTEND, (k_extend<false, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
         LAUNCH(k_bin, r->flat_blocks / 2, RT_BIN_BLOCK, R, r->ctl, cur, b == 0 ? 1 : 0);
         if (radiosity) LAUNCHK(RT_KID_SHADE, k_shade<true>, r->flat_blocks / 2, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
@@ -1449,7 +1466,7 @@ static int render_now(rt_renderer* r, int mode, int spp, uint64_t seed, uint64_t
     const uint32_t bmax = batch_limit(r, mode);
     int done = 0;
     const uint32_t tile_rows = r->R.np_pad / (r->R.tiles_x * 64u);
-    if (mode == RT_MODE_PATH && spp == 1 && RT_LANES > 1 && RT_SPLIT_FRAME && !r->filter.kind && tile_rows >= 2 && r->active_lane == 0) {
+    if (mode == RT_MODE_PATH && spp == 1 && r->lanes > 1 && RT_SPLIT_FRAME && !r->filter.kind && tile_rows >= 2 && r->active_lane == 0) {
         // One sample of the frame (upstream's render() per displayed frame, Main.cpp:79-137): the upper and the lower tile rows
         // go to the two lanes, so that the end of one half's launches overlaps the other half's work as batches do above.
         // Every pixel gets the same film += L either way; the filtered films gather across the cut and stay on one lane.
@@ -1474,7 +1491,7 @@ static int render_now(rt_renderer* r, int mode, int spp, uint64_t seed, uint64_t
         r->acc_pending = true;
         return RT_OK;
     }
-    if ((mode == RT_MODE_PATH || mode == RT_MODE_LIGHT) && spp >= 2 && RT_LANES > 1) {
+    if ((mode == RT_MODE_PATH || mode == RT_MODE_LIGHT) && spp >= 2 && r->lanes > 1) {
         // at least two batches, alternating between the two lanes (streams).  Path tracing chains its film accumulation by
         // an event (fixed fp32 sum order); the light tracer's splats are atomics and need no order (PSSMLT on two lanes measured no faster).
         int rc = ensure_other_lane(r);
@@ -1657,13 +1674,19 @@ extern "C" int rt_vpl_trace(rt_renderer* r, int n_vpls, uint64_t seed) {
     r->n_vpl = 0; r->R.vpl_slots = 0;
     if (n_vpls == 0) return RT_OK;
     int rc;
-    float4* vpl = nullptr; float4* gather = nullptr;
-    if ((rc = dev_alloc(r, &vpl, (size_t)n_vpls * 6 * 4))) return rc;
-    if (!r->R.gather) { if ((rc = dev_alloc(r, &gather, (size_t)r->R.cap * 4))) return rc; r->R.gather = gather; }
-    r->R.vpl = vpl;
-    uint32_t* sp = nullptr;
+    float4* gather = nullptr;
     int blocks = (n_vpls + 63) / 64;
-    if ((rc = dev_alloc(r, &sp, (size_t)blocks * 64 * std::max<uint32_t>(r->scene->host.max_stack2, 2)))) return rc;
+    // the record and walk-stack buffers stay with the renderer and are reused; they only grow (the old ones are freed)
+    if ((uint32_t)n_vpls > r->vpl_cap) {
+        for (void* old : { (void*)r->R.vpl, (void*)r->vpl_stack })
+            if (old) { (void)hipFree(old); r->allocs.erase(std::remove(r->allocs.begin(), r->allocs.end(), old), r->allocs.end()); }
+        r->R.vpl = nullptr; r->vpl_stack = nullptr; r->vpl_cap = 0;
+        if ((rc = dev_alloc(r, &r->R.vpl, (size_t)blocks * 64 * 6 * 4))) return rc;
+        if ((rc = dev_alloc(r, &r->vpl_stack, (size_t)blocks * 64 * std::max<uint32_t>(r->scene->host.max_stack2, 2)))) return rc;
+        r->vpl_cap = (uint32_t)blocks * 64u;
+    }
+    if (!r->R.gather) { if ((rc = dev_alloc(r, &gather, (size_t)r->R.cap * 4))) return rc; r->R.gather = gather; }
+    uint32_t* sp = r->vpl_stack;
     LAUNCH(k_vpl_trace, blocks, 64, r->scene->d, r->R, n_vpls, seed, sp, r->ctl);
     RT_HIP(hipGetLastError());
     { int frc_ = flush_pending(r); if (frc_) return frc_; }

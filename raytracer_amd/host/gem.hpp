@@ -288,6 +288,8 @@ inline Image decodePNG(const std::vector<uint8_t>& b, const std::string& name) {
         o += 12 + len;
     }
     if (!W || !H || idat.size() < 2) throw std::runtime_error(name + ": not a usable PNG");
+    if (W > (1u << 16) || H > (1u << 16)) throw std::runtime_error(name + ": PNG larger than 65536 pixels a side");   // keeps (stride + 1) * H far from wrapping
+    if (ctype == 3 && depth == 16) throw std::runtime_error(name + ": a palette PNG cannot be 16 bits deep");
     if (interlace) throw std::runtime_error(name + ": interlaced PNG is not supported by this host");
     int comps = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!comps || (depth != 8 && depth != 16 && !((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) throw std::runtime_error(name + ": unsupported PNG colour type / bit depth");

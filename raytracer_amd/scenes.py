@@ -298,17 +298,21 @@ def open_box(width=96, height=96, background="env"):
     return set_camera(s, (0, 1.0, 4.4), (0, 0.8, 0), (0, 1, 0), 40.0, width, height)
 
 
-def interior(variant="bathroom", detail=1.0, width=1920, height=1080, seed=1, conductor=False, dielectric=False):
+def interior(variant="bathroom", detail=1.0, width=1920, height=1080, seed=1, conductor=False, dielectric=False, glazed=False):
     """Closed-room stand-in for the bathroom / living-room scenes: ~1.0 M triangles at detail=1
     (triangle count scales ~detail^2), tessellated displaced fixtures, thin slats (blinds), glass bulbs,
     a mirror, a tiled floor with a bilinear checker texture, plastic/diffuse/glass/mirror materials and
     four ceiling panels.  Vertices carry a <=1e-3 seeded jitter so there are no exact coplanar duplicates.
 
-    The material mix of the default scene is SURVEY 8(d)'s (diffuse / glass / mirror / plastic): every estimator in it
-    is bounded, so the film is finite and the converged-image gate can run on it.  The two unbounded upstream BSDFs are
-    opt-in variants of the same geometry, reported separately: `conductor=True` makes the small sphere of the bathroom a
-    rough conductor, `dielectric=True` a rough ("frosted") dielectric, whose half-vector draw (Materials.h:571) yields
-    inf / NaN throughputs."""
+    The material mix of the default scene is SURVEY 8(d)'s (diffuse / glass / mirror / plastic), placed so that every
+    estimator in it stays finite and the converged-image gate can run on it.  Upstream's non-finite cases are opt-in variants
+    of the same geometry, reported separately: `conductor=True` makes the small sphere of the bathroom a rough conductor,
+    `dielectric=True` a rough ("frosted") dielectric, whose half-vector draw (Materials.h:571) yields inf / NaN
+    throughputs; `glazed=True` puts PlasticBSDF on the smooth-shaded curved fixtures as well.  On those, a camera ray
+    (whose direction upstream leaves un-normalised, |dir| ~ 1e-3, Scene.h:60) that meets the silhouette has wo.z < 3e-8 in
+    the shading frame, Fresnel rounds to exactly 1, kd = 0, the Phong term underflows and PlasticBSDF::sample returns
+    f = 0 with pdf = 0 (Materials.h:861-930): 0 / 0, about one NaN sample in 3 million at 1080p.  By default plastic
+    therefore sits on the flat-shaded parts (blinds, shelves), where that grazing angle has no measurable probability."""
     rng = np.random.default_rng(seed + (0 if variant == "bathroom" else 1000))
     b = _Builder()
     tex = [solid((0.8, 0.8, 0.78)),                       # 0 wall paint
@@ -323,14 +327,15 @@ def interior(variant="bathroom", detail=1.0, width=1920, height=1080, seed=1, co
             Material(DIFFUSE, 1),                                       # 1 floor
             Material(DIFFUSE, 2),                                       # 2 feature wall
             Material(DIFFUSE, 3, emission=(22.0, 20.0, 17.0)),          # 3 ceiling panels
-            Material(PLASTIC, 6, int_ior=1.5, ext_ior=1.0, roughness=0.05),   # 4 porcelain fixtures
+            Material(PLASTIC, 6, int_ior=1.5, ext_ior=1.0, roughness=0.05) if glazed   # 4 porcelain fixtures (curved, smooth normals)
+            else Material(DIFFUSE, 6),
             Material(GLASS, 3, int_ior=1.5, ext_ior=1.0),               # 5 glass
             Material(MIRROR, 3),                                        # 6 mirror
             Material(DIFFUSE, 4),                                       # 7
             Material(ORENNAYAR, 5, sigma=0.4),                          # 8
             Material(PLASTIC, 7, int_ior=1.4, ext_ior=1.0, roughness=0.2),    # 9 slats
             Material(DIELECTRIC, 3, int_ior=1.33, ext_ior=1.0, roughness=0.1) if dielectric  # 10 frosted (one-sided), opt-in
-            else Material(PLASTIC, 5, int_ior=1.33, ext_ior=1.0, roughness=0.1)]                # 10 glazed blue (the default)
+            else (Material(PLASTIC, 5, int_ior=1.33, ext_ior=1.0, roughness=0.1) if glazed else Material(DIFFUSE, 5))]   # 10 blue ball
     if conductor:
         mats.append(Material(CONDUCTOR, 3, roughness=0.05, eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14)))  # 11
     X, Y, Z = 4.0, 3.0, 3.0

@@ -31,7 +31,7 @@ def same_material(got, want: scenes.Material):
 
 @pytest.mark.parametrize("make,indexed", [
     (lambda: scenes.cornell(40, 30, with_specular=True), True),
-    (lambda: scenes.interior("bathroom", 0.06, 64, 36, conductor=True), True),
+    (lambda: scenes.interior("bathroom", 0.06, 64, 36, conductor=True, dielectric=True, glazed=True), True),
     (lambda: scenes.open_box(32, 32, "env"), False),
 ], ids=["cornell-spec", "bathroom", "envmap"])
 def test_loader_reproduces_exported_scene(tmp_path, make, indexed):

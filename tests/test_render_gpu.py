@@ -59,7 +59,7 @@ def test_full_size_frame_same_seed_including_non_finite_pixels():
     unnormalised directions give throughputs of 1e30, inf and NaN; Renderer.h:233 multiplies them with computeDirect's
     Colour(0), so a handful of pixels per sample are NaN upstream.  The GPU film must be non-finite in exactly those
     pixels; elsewhere the two sides follow the same paths up to libm-vs-ocml rounding (amplified where 1 - cos^2 cancels)."""
-    s = scenes.bathroom(1.0, 1920, 1080, dielectric=True)
+    s = scenes.bathroom(1.0, 1920, 1080, dielectric=True, glazed=True)
     want, st = orc.OracleScene(s).render(0, 1, seed=3, threads=16)
     sc = api.Scene(s, device_build=True)
     rt = api.RayTracer(sc); rt.render(api.PATH, 1, 3, 0); got, _ = rt.film(); cnt = rt.counters(); rt.close(); sc.close()
@@ -253,7 +253,7 @@ def test_full_size_light_tracing_same_seed():
 def test_full_size_radiosity_and_pssmlt_same_seed():
     """BASELINE config 5 shape on the bathroom-class 1080p frame: instant radiosity (2 light samples -> 5 VPLs) and one PSSMLT
     chain, same numbers on both sides.  The radiosity film also carries the rough dielectric's NaN pixels: same pixels."""
-    s = scenes.bathroom(1.0, 1920, 1080, dielectric=True)
+    s = scenes.bathroom(1.0, 1920, 1080, dielectric=True, glazed=True)
     o = orc.OracleScene(s)
     sc = api.Scene(s, device_build=True)
     n = o.vpl_trace(2, seed=9)
@@ -423,7 +423,7 @@ def test_instant_radiosity_same_seed():
 
 def test_bsdf_probes_match_oracle():
     """BSDF::sample / evaluate / PDF per material class on identical inputs and identical random numbers."""
-    s = scenes.interior("bathroom", 0.05, 64, 36, conductor=True)
+    s = scenes.interior("bathroom", 0.05, 64, 36, conductor=True, dielectric=True, glazed=True)
     o, sc = orc.OracleScene(s), api.Scene(s)
     rng = np.random.default_rng(0)
     n = 2000
