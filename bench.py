@@ -246,6 +246,7 @@ def main():
                 "traffic_is": "2 x FETCH_SIZE + WRITE_SIZE per k_extend launch (MI355X_MICROARCH.md: FETCH_SIZE tallies 128-B requests at 64 B on gfx950); "
                               "L2-miss traffic on the fabric, Infinity-Cache hits included - an upper bound on HBM bytes",
                 "ceilings": ceilings,
+                "shape": shape,
                 "bytes_per_ray": bytes_per_ray,
                 "nodes_per_ray": nodes_per_ray,
                 "tris_per_ray": tris_per_ray,

@@ -220,6 +220,10 @@ int rt_debug_bsdf_sample(rt_scene* scene, uint32_t material, const float* wo, co
 int rt_debug_bsdf_eval(rt_scene* scene, uint32_t material, const float* wo, const float* n, const float* uv,
                        const float* wi, size_t count, float* out4);
 int rt_debug_rng(uint64_t seed, uint64_t sample, uint32_t pixel, uint32_t stream, int n, float* out);
+/* EnvironmentMap's tabulated importance sampling (Lights.h:207-424) on the device, for scenes with an environment map:
+ * in3[count][3] -> out4[count][4].  which = 0: sample() / sampleDirectionFromLight() after their two draws (in = u0, u1, -;
+ * out = wi.xyz, pdf); 1: SampleContinuous (out = d0, d1, pdf, 0); 2: PDF(wi) (in = wi; out[0]). */
+int rt_debug_env(rt_scene* scene, int which, const float* in3, size_t count, float* out4);
 
 #ifdef __cplusplus
 }

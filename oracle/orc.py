@@ -73,6 +73,12 @@ def lib():
         L.orc_aabb_ray.restype = C.c_int
         L.orc_aabb_default_area.restype = C.c_float
         L.orc_texture_sample.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]
+        L.orc_env_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_env_probe.restype = C.c_int
+        L.orc_env_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_env_tables.restype = C.c_float
+        L.orc_trace_path.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_trace_path.restype = C.c_int
         _lib = L
     return _lib
 
@@ -193,6 +199,20 @@ class OracleScene:
         self.L.orc_bsdf_eval(self.h, mat, wo.ctypes.data, n.ctypes.data, uv.ctypes.data, wi.ctypes.data, out.ctypes.data)
         return out
 
+    def env_probe(self, which, in3):
+        """EnvironmentMap sample (0) / SampleContinuous (1) / PDF (2): in [n, 3] -> out [n, 4]."""
+        a = _f32(in3).reshape(-1, 3)
+        out = np.zeros((a.shape[0], 4), np.float32)
+        for i in range(a.shape[0]):
+            assert self.L.orc_env_probe(self.h, which, a[i].ctypes.data, out[i].ctypes.data) == 1, "scene has no environment map"
+        return out
+
+    def env_tables(self, nu, nv):
+        """(conditional pdfs [nv, nu], marginal pdfs [nv], funcInt) of EnvironmentMap::build (Lights.h:207-253)."""
+        cond, marg = np.zeros((nv, nu), np.float32), np.zeros(nv, np.float32)
+        f = self.L.orc_env_tables(self.h, cond.ctypes.data, marg.ctypes.data)
+        return cond, marg, float(f)
+
     def texture_sample(self, tex, u, v):
         out = np.zeros(3, np.float32)
         self.L.orc_texture_sample(self.h, tex, u, v, out.ctypes.data)
@@ -238,6 +258,11 @@ def ref():
         L.ref_matrix.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         L.ref_mul_point_div.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ref_mtrandom.argtypes = [C.c_uint, C.c_int, C.c_void_p]
+        if hasattr(L, "ref_vec2_index"):   # round-2 probes (an older _ref build lacks them)
+            L.ref_vec2_index.argtypes = [C.c_float, C.c_float, C.c_int]
+            L.ref_vec2_index.restype = C.c_int
+            L.ref_matrix_apply.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+            L.ref_tri_centre.argtypes = [C.c_void_p, C.c_void_p]
         _ref = L
     return _ref
 

@@ -223,6 +223,29 @@ void ref_mul_point_div(const float* m16, const float* p4, float* out3) {
     out3[0] = r.x; out3[1] = r.y; out3[2] = r.z;
 }
 
+// Vec2::operator[] (Sampling.h:199-210): declared to return int, so the float coordinate is truncated.  EnvironmentMap's
+// tabulated sampling reads its 2-D draw through it (Lights.h), which is what the device's "net effect" restatement rests on.
+int ref_vec2_index(float x, float y, int i) { Vec2 v(x, y); return v[i]; }
+
+// The instance transform of loadInstance (SceneLoader.h:196-219) as Core.h performs it: which = 0 mulPoint(v), 1 mulVec(v),
+// 2 transpose() (out16), 3 invert().transpose().mulVec(v).normalize() (a loaded normal), 4 operator*(second matrix in v16) (out16)
+void ref_matrix_apply(int which, const float* m16, const float* v, float* out) {
+    Matrix m; memcpy(m.m, m16, 64);
+    if (which == 0) { Vec3 r = m.mulPoint(Vec3(v[0], v[1], v[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+    else if (which == 1) { Vec3 r = m.mulVec(Vec3(v[0], v[1], v[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+    else if (which == 2) { Matrix t = m.transpose(); memcpy(out, t.m, 64); }
+    else if (which == 3) { Matrix t = m.invert(); t = t.transpose(); Vec3 r = t.mulVec(Vec3(v[0], v[1], v[2])); r = r.normalize(); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+    else { Matrix b; memcpy(b.m, v, 64); Matrix t = m * b; memcpy(out, t.m, 64); }
+}
+
+// Triangle::centre (Geometry.h:83-86; Vec3 operator/ also divides w) and the area test of loadInstance (t.area > 0, SceneLoader.h:229)
+void ref_tri_centre(const float* tri24, float* out5) {
+    Triangle t;
+    t.init(make_vertex(tri24), make_vertex(tri24 + 8), make_vertex(tri24 + 16), 0);
+    Vec3 c = t.centre();
+    out5[0] = c.x; out5[1] = c.y; out5[2] = c.z; out5[3] = c.w; out5[4] = t.area;
+}
+
 // MTRandom (Sampling.h:23-36): first n draws for a seed
 void ref_mtrandom(unsigned seed, int n, float* out) {
     MTRandom r(seed);

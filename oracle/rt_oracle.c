@@ -272,6 +272,8 @@ struct orc_scene {
     V3 origin, view_dir; float Afilm;
     VPL* vpls; int nvpls, cap_vpls;
     int filter; /* 0 BoxFilter (Renderer.h:61), 1 GaussianFilter, 2 MitchellNetravaliFilter */
+    /* EnvironmentMap::build (Lights.h:207-253): per-row-normalised pdfs, row pdfs, total; NULL without an environment map */
+    float* env_cond; float* env_marg; float env_func_int; int env_nu, env_nv;
 };
 
 /* ---------------------------------------------------------------- BVH build (ref: Geometry.h:310-438) */
@@ -827,6 +829,99 @@ static float bg_power(const orc_scene* s) {
     return total * 4.0f * M_PI;
 }
 
+/* ---- EnvironmentMap's tabulated importance sampling (Lights.h:207-253, :306-325, :347-424), as written upstream.
+ * build() leaves per-row-normalised PDFS in `conditional_cdf` and row pdfs in `marginal_cdf`; Sample1D walks a running sum
+ * over them.  Everything the tables produce then passes through Vec2::operator[], which returns int (Sampling.h:204,
+ * pinned by tests/golden/scalars_r2.npz: 0 for every coordinate in [0, 1)), so sample() / sampleDirectionFromLight() / PDF()
+ * end up at theta = 0: wi = (0, 1, 0) and pdf = (table pdf) * 2 pi^2 / sin(0) = +inf.  The steps are kept so that the cases
+ * that do not collapse (a coordinate of exactly 1, a walk that falls off the end of the table) come out as upstream's. */
+static void env_build(orc_scene* s) {
+    const Texture* e = &s->tex[s->bg.env_tex];
+    int nu = e->width, nv = e->height;
+    s->env_nu = nu; s->env_nv = nv;
+    float* func = (float*)malloc(sizeof(float) * (size_t)nu * nv);
+    s->env_cond = (float*)malloc(sizeof(float) * (size_t)nu * nv);
+    s->env_marg = (float*)malloc(sizeof(float) * (size_t)nv);
+    float funcInt = 0.0f;
+    for (int v = 0; v < nv; ++v) {
+        float theta = (v + 0.5f) / nv * M_PI;
+        float sinTheta = sinf(theta);
+        for (int u = 0; u < nu; ++u) {
+            int idx = v * nu + u;
+            float lum = clum(e->texels[idx]);
+            func[idx] = lum * sinTheta;
+            funcInt += func[idx];
+        }
+    }
+    for (int v = 0; v < nv; ++v) {
+        float* row = s->env_cond + (size_t)v * nu;
+        float sum = 0.0f;
+        for (int u = 0; u < nu; ++u) { row[u] = func[v * nu + u]; sum += row[u]; }
+        if (sum > 0.0f) for (int u = 0; u < nu; ++u) row[u] /= sum;
+    }
+    for (int v = 0; v < nv; ++v) {
+        float sum = 0.0f;
+        for (int u = 0; u < nu; ++u) sum += func[v * nu + u];
+        s->env_marg[v] = sum;
+    }
+    if (funcInt > 0.0f) for (int v = 0; v < nv; ++v) s->env_marg[v] /= funcInt;
+    s->env_func_int = funcInt;
+    free(func);
+}
+static float env_sample1d(const float* dist, int n, float u, float* pdf, int* offset) { /* Lights.h:306-325 */
+    float cdf = 0.0f;
+    int index = 0;
+    for (int i = 0; i < n; i++) {
+        cdf += dist[i];
+        if (u <= cdf) { index = i; break; }
+    }
+    index = index < n - 1 ? index : n - 1;
+    if (offset) *offset = index;
+    if (pdf) *pdf = dist[index] / (float)n;   /* dist[index] / dist.size(): size_t -> float */
+    float t = (u - (cdf - dist[index])) / dist[index];
+    return (index + t) / (float)n;
+}
+static void env_sample_continuous(const orc_scene* s, float u0, float u1, float* pdf, float* d0, float* d1) { /* Lights.h:347-356 */
+    float pdfs[2];
+    int v;
+    *d1 = env_sample1d(s->env_marg, s->env_nv, u1, &pdfs[1], &v);
+    *d0 = env_sample1d(s->env_cond + (size_t)v * s->env_nu, s->env_nu, u0, &pdfs[0], NULL);
+    *pdf = pdfs[0] * pdfs[1];
+}
+/* int Vec2::operator[] (Sampling.h:204): float -> int conversion; NaN (a zero-pdf entry picked by u == 0) is undefined upstream, 0 here */
+static int vec2_index(float x) { return (x != x) ? 0 : (int)x; }
+static V3 env_uv_to_direction(float u, float v) { /* Lights.h:366-374 */
+    float theta = v * M_PI;
+    float phi = u * 2.0f * M_PI;
+    float sinTheta = sinf(theta), cosTheta = cosf(theta), sinPhi = sinf(phi), cosPhi = cosf(phi);
+    return v3(sinTheta * cosPhi, cosTheta, sinTheta * sinPhi);
+}
+/* EnvironmentMap::sample / sampleDirectionFromLight after their two draws (Lights.h:385-399, :411-424) */
+static V3 env_sample_dir(const orc_scene* s, float u0, float u1, float* pdf) {
+    float d0, d1;
+    env_sample_continuous(s, u0, u1, pdf, &d0, &d1);
+    int iu = vec2_index(d0), iv = vec2_index(d1);            /* uv[0], uv[1] */
+    V3 wi = env_uv_to_direction((float)iu, (float)iv);
+    float theta = iv * M_PI;
+    float sinTheta = sinf(theta);
+    *pdf *= (2.0f * M_PI * M_PI) / sinTheta;
+    return wi;
+}
+static float env_pdf(const orc_scene* s, V3 wi) { /* EnvironmentMap::PDF, PdfUV, DirectionToUV (Lights.h:359-363, :377-383, :402-409) */
+    float u = atan2f(wi.z, wi.x);
+    u = (u < 0.0f) ? u + (2.0f * M_PI) : u;
+    u = u / (2.0f * M_PI);
+    float v = acosf(wi.y) / M_PI;
+    int p0 = vec2_index(u), p1 = vec2_index(v);
+    int iu = p0 * s->env_nu, iv = p1 * s->env_nv;             /* static_cast<int>(p[0] * nu): int * int */
+    iu = iu < 0 ? 0 : (iu > s->env_nu - 1 ? s->env_nu - 1 : iu);
+    iv = iv < 0 ? 0 : (iv > s->env_nv - 1 ? s->env_nv - 1 : iv);
+    float pdfUV = (s->env_cond[(size_t)iv * s->env_nu + iu] * s->env_nu * s->env_nv) / s->env_func_int;
+    float theta = p1 * M_PI;
+    float sinTheta = sinf(theta);
+    return pdfUV * (2.0f * M_PI * M_PI) / sinTheta;
+}
+
 /* Scene::sampleLight (Scene.h:144) */
 static const LightRef* sample_light(const orc_scene* s, Rng* rng, float* pmf) {
     *pmf = 1.f / s->nlights;
@@ -861,13 +956,8 @@ static V3 light_sample(const orc_scene* s, const LightRef* l, Rng* rng, Col* emi
         *emitted = col(s->bg.colour[0], s->bg.colour[1], s->bg.colour[2]);
         return wi;
     }
-    /* EnvironmentMap::sample (Lights.h:385-399): Vec2::operator[] returns int
-     * (Sampling.h:204), so uv == (0,0) for every draw: wi = (0,1,0), sin(theta) = 0
-     * and pdf = +inf (or NaN) -- the NEE term of an environment map is 0.  Round 1
-     * restates that net effect; the tabulated tables are a SURVEY §8(f) "next" row. */
-    (void)r1; (void)r2;
-    *pdf = INFINITY;
-    V3 wi = v3(0, 1, 0);
+    /* EnvironmentMap::sample (Lights.h:385-399) */
+    V3 wi = env_sample_dir(s, r1, r2, pdf);
     *emitted = bg_evaluate(s, wi);
     return wi;
 }
@@ -890,8 +980,7 @@ static V3 light_sample_direction(const orc_scene* s, const LightRef* l, Rng* rng
         return frame_to_world(&fr, wi);
     }
     if (l->kind == 1) { V3 wi = uniform_sample_sphere(r1, r2); *pdf = uniform_sphere_pdf(); return wi; } /* Lights.h:130 */
-    *pdf = INFINITY; /* Lights.h:411-424, same Vec2 truncation as above */
-    return v3(0, 1, 0);
+    return env_sample_dir(s, r1, r2, pdf); /* Lights.h:411-424 */
 }
 
 /* ---------------------------------------------------------------- camera (ref: Scene.h:14-79) */
@@ -1411,6 +1500,7 @@ orc_scene* orc_scene_create(const float* verts, const uint32_t* tri_mat, uint32_
         memcpy(s->tex[i].texels, tex[i].rgb, sizeof(Col) * n);
     }
     if (bg) s->bg = *bg;
+    if (bg && bg->kind == 1) env_build(s); /* EnvironmentMap's constructor (Lights.h:144-151) */
     /* Scene::init: background light first if it has power (Scene.h:164) */
     s->lights = (LightRef*)malloc(sizeof(LightRef) * ((size_t)ntris + 1));
     if (bg && bg_power(s) > 0) { s->lights[s->nlights].kind = bg->kind == 0 ? 1 : 2; s->lights[s->nlights].tri = 0; s->nlights++; }
@@ -1431,6 +1521,7 @@ void orc_scene_destroy(orc_scene* s) {
     if (!s) return;
     for (uint32_t i = 0; i < s->ntex; i++) free(s->tex[i].texels);
     free(s->tex); free(s->tris); free(s->nodes); free(s->leaf_tris); free(s->mats); free(s->lights); free(s->vpls);
+    free(s->env_cond); free(s->env_marg);
     free(s);
 }
 void orc_scene_info(orc_scene* s, int* st) {
@@ -1530,6 +1621,28 @@ void orc_bsdf_eval(orc_scene* s, uint32_t mat, const float* wo, const float* n, 
     V3 w = v3(wi[0], wi[1], wi[2]);
     Col f = bsdf_eval(s, &sd, w);
     out[0] = f.r; out[1] = f.g; out[2] = f.b; out[3] = bsdf_pdf(s, &sd, w);
+}
+/* Triangle::centre (Geometry.h:83-86) + area after Triangle::init: out5 = centre.xyz, centre.w (Vec3 / divides w too), area */
+void orc_tri_centre(const float* tri24, float* out5) {
+    Tri t; tri_init(&t, tri24, 0);
+    V3 c = tri_centre(&t);
+    out5[0] = c.x; out5[1] = c.y; out5[2] = c.z; out5[3] = 1.0f / 3.0f; out5[4] = t.area;
+}
+/* EnvironmentMap probes: which = 0 sample() after its two draws (out4 = wi, pdf), 1 SampleContinuous (out4 = d0, d1, pdf, 0),
+ * 2 PDF(wi) with in3 = wi (out4[0]); returns 0 without an environment map */
+int orc_env_probe(orc_scene* s, int which, const float* in, float* out4) {
+    if (!s->env_cond) return 0;
+    if (which == 0) { float pdf; V3 w = env_sample_dir(s, in[0], in[1], &pdf); out4[0] = w.x; out4[1] = w.y; out4[2] = w.z; out4[3] = pdf; }
+    else if (which == 1) { float pdf, d0, d1; env_sample_continuous(s, in[0], in[1], &pdf, &d0, &d1); out4[0] = d0; out4[1] = d1; out4[2] = pdf; out4[3] = 0; }
+    else { out4[0] = env_pdf(s, v3(in[0], in[1], in[2])); out4[1] = out4[2] = out4[3] = 0; }
+    return 1;
+}
+/* the tables themselves: cond[nv * nu], marg[nv]; returns funcInt */
+float orc_env_tables(orc_scene* s, float* cond, float* marg) {
+    if (!s->env_cond) return 0.0f;
+    if (cond) memcpy(cond, s->env_cond, sizeof(float) * (size_t)s->env_nu * s->env_nv);
+    if (marg) memcpy(marg, s->env_marg, sizeof(float) * (size_t)s->env_nv);
+    return s->env_func_int;
 }
 void orc_rng_floats(uint64_t seed, uint64_t sample, uint32_t pixel, uint32_t stream, int n, float* out) {
     Rng r = rng_make(seed, sample, pixel, stream);

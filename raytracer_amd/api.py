@@ -56,7 +56,7 @@ SYMBOLS = [
     "rt_renderer_create", "rt_renderer_destroy", "rt_render", "rt_film_clear", "rt_film_spp", "rt_film_read", "rt_film_bind",
     "rt_film_set_spp", "rt_vpl_trace", "rt_vpl_count", "rt_render_counters", "rt_renderer_sync", "rt_film_save_hdr",
     "rt_film_tonemap", "rt_profile_enable", "rt_profile_read", "rt_debug_bsdf_sample", "rt_debug_bsdf_eval", "rt_debug_rng", "rt_matrix_invert", "rt_scene_create_ex",
-    "rt_renderer_set_filter", "rt_render_aov", "rt_intersect_closest_noalloc", "rt_renderer_set_streams",
+    "rt_renderer_set_filter", "rt_render_aov", "rt_intersect_closest_noalloc", "rt_renderer_set_streams", "rt_debug_env",
 ]
 
 
@@ -121,6 +121,7 @@ def lib():
         _sig(L, "rt_debug_bsdf_sample", [vp, C.c_uint32, vp, vp, vp, vp, sz, vp])
         _sig(L, "rt_debug_bsdf_eval", [vp, C.c_uint32, vp, vp, vp, vp, sz, vp])
         _sig(L, "rt_debug_rng", [u64, u64, C.c_uint32, C.c_uint32, i32, vp])
+        _sig(L, "rt_debug_env", [vp, i32, vp, sz, vp])
         _lib = L
     return _lib
 
@@ -234,6 +235,13 @@ class Scene:
         out = np.zeros((wo.shape[0], 7), np.float32)
         _check(self.L.rt_debug_bsdf_sample(self.h, material, wo.ctypes.data, n.ctypes.data, uv.ctypes.data, kc.ctypes.data,
                                            wo.shape[0], out.ctypes.data), "rt_debug_bsdf_sample")
+        return out
+
+    def env_probe(self, which, in3):
+        """EnvironmentMap sample (0) / SampleContinuous (1) / PDF (2) on the device: in [n, 3] -> out [n, 4]."""
+        a = _f32(in3).reshape(-1, 3)
+        out = np.zeros((a.shape[0], 4), np.float32)
+        _check(self.L.rt_debug_env(self.h, which, a.ctypes.data, a.shape[0], out.ctypes.data), "rt_debug_env")
         return out
 
     def bsdf_eval(self, material, wo, n, uv, wi):

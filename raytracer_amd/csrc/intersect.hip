@@ -189,6 +189,8 @@ extern "C" int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_
         (rc = upload(s, h.nodes2, &d.nodes2)) || (rc = upload(s, h.mats, &d.mats)) || (rc = upload(s, h.tex, &d.tex)) ||
         (rc = upload(s, h.texels, &d.texels)) || (rc = upload(s, h.lights, &d.lights)))
         return fail(rc);
+    d.env_cond = nullptr; d.env_marg = nullptr; d.env_func_int = h.env_func_int; d.env_nu = h.env_nu; d.env_nv = h.env_nv;
+    if (!h.env_cond.empty() && ((rc = upload(s, h.env_cond, &d.env_cond)) || (rc = upload(s, h.env_marg, &d.env_marg)))) return fail(rc);
     d.n_tris = (uint32_t)h.tris.size(); d.n_lights = (uint32_t)h.lights.size();
     d.n_nodes4 = (uint32_t)h.nodes4.size(); d.n_nodes2 = (uint32_t)h.nodes2.size();
     d.root_ref = d.n_tris ? 0u : RT_REF_EMPTY;

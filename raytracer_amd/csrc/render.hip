@@ -406,8 +406,25 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_OCC) void k_shade(DScene S
                         sh_c = make_float4(cc.r, cc.g, cc.b, __uint_as_float(nfb));
                     }
                 }
-                // kind 2 (EnvironmentMap::sample): Vec2::operator[] truncates to int upstream (Sampling.h:204), so
-                // wi = (0,1,0) with pdf = inf and the term is 0; the two draws above are still consumed.
+                else {   // EnvironmentMap::sample (Lights.h:385-399): tabulated draw, read through Vec2::operator[]'s int (env_sample_dir)
+                    float pdf;
+                    f3 wi = env_sample_dir(S, r1, r2, pdf);
+                    col3 emitted = bg_evaluate(S, wi);
+                    float G = smaxf_w(dot3(wi, sd.sN), 0.0f);
+                    if (G > 0) {
+                        col3 cd = ((bsdf_eval(S, sd, wi) * emitted) * G) / (pmf * pdf);
+                        col3 cc = T * cd;
+                        // pdf is +inf for every draw whose table coordinates truncate to 0, i.e. the term is exactly 0 whether or not
+                        // Scene::visible finds the sky: such a request is not queued (upstream traces it and adds 0)
+                        if (!(cc.r == 0.0f && cc.g == 0.0f && cc.b == 0.0f)) {
+                            f3 p2 = sd.x + (wi * 10000.0f);
+                            want_shadow = true;
+                            sh_a = make_float4(sd.x.x, sd.x.y, sd.x.z, __uint_as_float(path));
+                            sh_b = make_float4(p2.x, p2.y, p2.z, 0);
+                            sh_c = make_float4(cc.r, cc.g, cc.b, __uint_as_float(nfb));
+                        }
+                    }
+                }
             }
             if (nfb) {
                 if (want_shadow) atomicOr(&ctl->nf_shadow, 1u);   // k_connect adds T * 0 when the sample is occluded
@@ -815,6 +832,20 @@ __global__ __launch_bounds__(RT_BLOCK) void k_aov(DScene S, RBuf R, Ctl* ctl, in
                                 sh_b = make_float4(p2.x, p2.y, p2.z, 0);
                                 sh_c = make_float4(cd.r, cd.g, cd.b, 0);
                             }
+                        } else {   // EnvironmentMap::sample, as in k_shade
+                            float pdf;
+                            f3 wi = env_sample_dir(S, r1, r2, pdf);
+                            float G = smaxf_w(dot3(wi, sd.sN), 0.0f);
+                            if (G > 0) {
+                                col3 cd = ((bsdf_eval(S, sd, wi) * bg_evaluate(S, wi)) * G) / (pmf * pdf);
+                                if (!(cd.r == 0.0f && cd.g == 0.0f && cd.b == 0.0f)) {
+                                    f3 p2 = sd.x + (wi * 10000.0f);
+                                    want_shadow = true;
+                                    sh_a = make_float4(sd.x.x, sd.x.y, sd.x.z, __uint_as_float(i));
+                                    sh_b = make_float4(p2.x, p2.y, p2.z, 0);
+                                    sh_c = make_float4(cd.r, cd.g, cd.b, 0);
+                                }
+                            }
                         }
                     }
                 } else if (mode == RT_MODE_AOV_ALBEDO) out = bg_evaluate(S, d);
@@ -862,13 +893,14 @@ __device__ inline void light_emit(const DScene& S, Rng& rng, float N_vpl, bool f
         if (light.kind == 1) pdfPos = (float)(4 * RT_PI * S.scene_radius * S.scene_radius);  // sic
         else pdfPos = (float)(1.0f / (4 * RT_PI * (S.scene_radius * S.scene_radius)));
         if (light.kind == 1) { wi = uniform_sample_sphere(r3, r4); pdfDir = uniform_sphere_pdf(); }
-        else { wi = mk3(0, 1, 0); pdfDir = RT_INF; }                   // Vec2 truncation, see k_shade
-        emitted = light.kind == 1 ? mkc(S.bg_colour[0], S.bg_colour[1], S.bg_colour[2]) : bg_evaluate(S, mk3(0, 1, 0));
+        else wi = env_sample_dir(S, r3, r4, pdfDir);                   // sampleDirectionFromLight (Lights.h:411-424)
+        emitted = mkc(S.bg_colour[0], S.bg_colour[1], S.bg_colour[2]);
         ln = -p;                                                       // normal(shadingData, p) = -p (Lights.h:114)
         if (!for_vpl) Le = bg_evaluate(S, -wi) / pdfPos;
     }
-    if (for_vpl) {  // traceVPLs (Renderer.h:788-797): light->sample() consumes two more draws, emitted = emission
-        (void)rt_rng_next(rng); (void)rt_rng_next(rng);
+    if (for_vpl) {  // traceVPLs (Renderer.h:788-797): light->sample() draws two more numbers; emitted = what it returns as reflectedColour
+        const float r5 = rt_rng_next(rng), r6 = rt_rng_next(rng);
+        if (light.kind == 2) { float pdf_; emitted = bg_evaluate(S, env_sample_dir(S, r5, r6, pdf_)); }
         Le = (emitted * fabsf(dot3(wi, ln))) / (pmf * pdfPos * pdfDir * N_vpl);
     }
     ok = true;
@@ -1111,6 +1143,17 @@ __global__ void k_debug_bsdf(DScene S, uint32_t mat, const float* wo, const floa
         float* o = out + i * 4;
         o[0] = f.r; o[1] = f.g; o[2] = f.b; o[3] = bsdf_pdf(S, sd, w);
     }
+}
+
+// EnvironmentMap probes: which = 0 sample() after its two draws (wi, pdf), 1 SampleContinuous (d0, d1, pdf, 0), 2 PDF(wi)
+__global__ void k_debug_env(DScene S, int which, const float* in, size_t count, float* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float* a = in + i * 3;
+    float* o = out + i * 4;
+    if (which == 0) { float pdf; f3 w = env_sample_dir(S, a[0], a[1], pdf); o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = pdf; }
+    else if (which == 1) { float pdf, d0, d1; env_sample_continuous(S, a[0], a[1], pdf, d0, d1); o[0] = d0; o[1] = d1; o[2] = pdf; o[3] = 0; }
+    else { o[0] = env_pdf(S, mk3(a[0], a[1], a[2])); o[1] = o[2] = o[3] = 0; }
 }
 
 // ================================================================================================= host side
@@ -1769,6 +1812,24 @@ static int debug_bsdf(rt_scene* s, uint32_t mat, const float* wo, const float* n
     RT_HIP(hipDeviceSynchronize());
     RT_HIP(hipMemcpy(out, d_out, count * ow * 4, hipMemcpyDeviceToHost));
     (void)hipFree(d_wo); (void)hipFree(d_n); (void)hipFree(d_uv); (void)hipFree(d_x); (void)hipFree(d_out);
+    return RT_OK;
+}
+extern "C" int rt_debug_env(rt_scene* s, int which, const float* in3, size_t count, float* out4) {
+    if (!s || !in3 || !out4 || which < 0 || which > 2) { rt_set_error("rt_debug_env: bad argument"); return RT_ERR_INVALID; }
+    if (!s->d.env_cond) { rt_set_error("rt_debug_env: the scene has no environment map"); return RT_ERR_INVALID; }
+    if (count == 0) return RT_OK;
+    float *d_in = nullptr, *d_out = nullptr;
+    RT_HIP(hipMalloc((void**)&d_in, count * 12));
+    if (hipMalloc((void**)&d_out, count * 16) != hipSuccess) { (void)hipFree(d_in); rt_set_error("rt_debug_env: out of device memory"); return RT_ERR_NOMEM; }
+    hipError_t e = hipMemcpy(d_in, in3, count * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_env, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, 0, s->d, which, (const float*)d_in, count, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out4, d_out, count * 16, hipMemcpyDeviceToHost);
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    if (e != hipSuccess) return rt_hip_fail(e, "rt_debug_env");
     return RT_OK;
 }
 extern "C" int rt_debug_bsdf_sample(rt_scene* s, uint32_t mat, const float* wo, const float* n, const float* uv, const uint32_t* kc, size_t count, float* out) {

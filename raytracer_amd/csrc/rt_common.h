@@ -90,6 +90,9 @@ struct DScene {
     float bg_colour[3];
     uint32_t bg_kind; int32_t bg_tex;
     float scene_centre[3], scene_radius;   // SceneBounds (Lights.h:12, SceneLoader.h:286-287)
+    const float* env_cond;    // EnvironmentMap's tables (Lights.h:207-253); null without an environment map
+    const float* env_marg;
+    float env_func_int; int32_t env_nu, env_nv;
     DCamera cam;
 };
 

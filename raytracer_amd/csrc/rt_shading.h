@@ -396,6 +396,61 @@ __device__ inline col3 bg_evaluate(const DScene& S, f3 wi) {
     return tex_sample(S, S.bg_tex, u, v);
 }
 
+// ---- EnvironmentMap's tabulated importance sampling (Lights.h:306-325, :347-424) over the tables of EnvironmentMap::build
+// (scene_build.cpp).  Upstream reads every coordinate the tables produce through Vec2::operator[], which returns int
+// (Sampling.h:204; pinned from the compiled reference in tests/golden/scalars_r2.npz): for coordinates in [0, 1) that is 0,
+// so sample() / sampleDirectionFromLight() / PDF() end at theta = 0 -- wi = (0, 1, 0), pdf = (table pdf) * 2 pi^2 / 0 = +inf.
+// The steps are kept so that the draws that do not collapse (a coordinate of exactly 1, a walk that runs off the end of
+// a table whose pdfs sum to less than the draw) come out as upstream's.
+__device__ inline float env_sample1d(const float* __restrict__ dist, int n, float u, float* pdf, int* offset) {
+    float cdf = 0.0f;
+    int index = 0;
+    for (int i = 0; i < n; i++) {
+        cdf += dist[i];
+        if (u <= cdf) { index = i; break; }
+    }
+    index = index < n - 1 ? index : n - 1;
+    if (offset) *offset = index;
+    if (pdf) *pdf = dist[index] / (float)n;
+    float t = (u - (cdf - dist[index])) / dist[index];
+    return (index + t) / (float)n;
+}
+__device__ inline void env_sample_continuous(const DScene& S, float u0, float u1, float& pdf, float& d0, float& d1) {
+    float p0, p1;
+    int v;
+    d1 = env_sample1d(S.env_marg, S.env_nv, u1, &p1, &v);
+    d0 = env_sample1d(S.env_cond + (size_t)v * S.env_nu, S.env_nu, u0, &p0, nullptr);
+    pdf = p0 * p1;
+}
+__device__ __forceinline__ int vec2_index(float x) { return (x != x) ? 0 : (int)x; }   // NaN: undefined upstream, 0 here and in the oracle
+__device__ inline f3 env_sample_dir(const DScene& S, float u0, float u1, float& pdf) {
+    float d0, d1;
+    env_sample_continuous(S, u0, u1, pdf, d0, d1);
+    const int iu = vec2_index(d0), iv = vec2_index(d1);
+    float theta = (float)((double)(float)iv * RT_PI);              // UVToDirection (Lights.h:366-374)
+    float phi = (float)((double)((float)iu * 2.0f) * RT_PI);
+    float sinTheta = sinf(theta), cosTheta = cosf(theta), sinPhi = sinf(phi), cosPhi = cosf(phi);
+    f3 wi = mk3(sinTheta * cosPhi, cosTheta, sinTheta * sinPhi);
+    float theta2 = (float)((double)iv * RT_PI);
+    float sinTheta2 = sinf(theta2);
+    pdf = (float)((double)pdf * ((double)(2.0f) * RT_PI * RT_PI / (double)sinTheta2));   // Jacobian (Lights.h:396)
+    return wi;
+}
+__device__ inline float env_pdf(const DScene& S, f3 wi) {   // EnvironmentMap::PDF (Lights.h:402-409) with PdfUV / DirectionToUV
+    float u = atan2f(wi.z, wi.x);
+    u = (u < 0.0f) ? (float)(u + (2.0f * RT_PI)) : u;
+    u = (float)(u / (2.0f * RT_PI));
+    float v = (float)(acosf(wi.y) / RT_PI);
+    const int p0 = vec2_index(u), p1 = vec2_index(v);
+    int iu = p0 * S.env_nu, iv = p1 * S.env_nv;
+    iu = iu < 0 ? 0 : (iu > S.env_nu - 1 ? S.env_nu - 1 : iu);
+    iv = iv < 0 ? 0 : (iv > S.env_nv - 1 ? S.env_nv - 1 : iv);
+    float pdfUV = (S.env_cond[(size_t)iv * S.env_nu + iu] * S.env_nu * S.env_nv) / S.env_func_int;
+    float theta = (float)((double)p1 * RT_PI);
+    float sinTheta = sinf(theta);
+    return (float)((double)pdfUV * ((double)(2.0f) * RT_PI * RT_PI) / (double)sinTheta);
+}
+
 // ---- triangle helpers on device records
 __device__ __forceinline__ f3 tri_gnormal(const DTri& t) {  // Geometry.h:175
     f3 n = ld3(t.n);

@@ -310,6 +310,35 @@ bool host_scene_build(const rt_scene_desc& d, HostScene& hs, std::string& err, B
     }
     hs.bg_kind = d.background.kind; hs.bg_tex = d.background.env_tex;
     memcpy(hs.bg_colour, d.background.colour, 12);
+    if (d.background.kind == 1) {   // EnvironmentMap::build (Lights.h:207-253), same float operations in the same order
+        const rt_texture& e = d.textures[d.background.env_tex];
+        const int nu = e.width, nv = e.height;
+        std::vector<float> func((size_t)nu * nv);
+        float funcInt = 0.0f;
+        for (int v = 0; v < nv; ++v) {
+            float theta = (v + 0.5f) / nv * M_PI;
+            float sinTheta = sinf(theta);
+            for (int u = 0; u < nu; ++u) {
+                size_t idx = (size_t)v * nu + u;
+                func[idx] = lum(e.rgb + idx * 3) * sinTheta;
+                funcInt += func[idx];
+            }
+        }
+        hs.env_cond.resize((size_t)nu * nv); hs.env_marg.resize((size_t)nv);
+        for (int v = 0; v < nv; ++v) {
+            float* row = hs.env_cond.data() + (size_t)v * nu;
+            float sum = 0.0f;
+            for (int u = 0; u < nu; ++u) { row[u] = func[(size_t)v * nu + u]; sum += row[u]; }
+            if (sum > 0.0f) for (int u = 0; u < nu; ++u) row[u] /= sum;
+        }
+        for (int v = 0; v < nv; ++v) {
+            float sum = 0.0f;
+            for (int u = 0; u < nu; ++u) sum += func[(size_t)v * nu + u];
+            hs.env_marg[v] = sum;
+        }
+        if (funcInt > 0.0f) for (int v = 0; v < nv; ++v) hs.env_marg[v] /= funcInt;
+        hs.env_func_int = funcInt; hs.env_nu = nu; hs.env_nv = nv;
+    }
 
     // reference tree
     Builder b; b.verts = d.verts; b.n = d.n_tris;

@@ -25,6 +25,9 @@ struct HostScene {
     float centre[3], radius = 0;
     float bg_colour[3] = { 0, 0, 0 };
     uint32_t bg_kind = 0; int32_t bg_tex = -1;
+    // EnvironmentMap::build (Lights.h:207-253): per-row-normalised pdfs [nv][nu], row pdfs [nv], their total; empty without an env map
+    std::vector<float> env_cond, env_marg;
+    float env_func_int = 0; int32_t env_nu = 0, env_nv = 0;
     double build_seconds = 0;
 };
 

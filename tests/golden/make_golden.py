@@ -90,5 +90,46 @@ def main():
     print({k: v.tolist() for k, v in out.items()})
 
 
+def pins_r2():
+    """Round-2 pins from the compiled reference (Sampling.h Vec2, Core.h Matrix helpers as loadInstance uses them,
+    Triangle::centre): tests/golden/scalars_r2.npz.   python tests/golden/make_golden.py r2"""
+    import ctypes as C
+    L = orc.ref()
+    rng = np.random.default_rng(21)
+    xy = rng.uniform(0, 1, (256, 2)).astype(np.float32)
+    xy = np.concatenate([xy, np.array([[0.0, 0.99999994], [1.0, 1.5], [2.75, -0.5], [-1.25, 3.0]], np.float32)])
+    vec2 = np.array([[L.ref_vec2_index(C.c_float(x), C.c_float(y), i) for i in (0, 1)] for x, y in xy], np.int32)
+    ang = 0.7
+    worlds = np.stack([
+        np.array([[2 * np.cos(ang), 0, 2 * np.sin(ang), 0.5], [0, 1.5, 0, -1.0], [-np.sin(ang), 0, np.cos(ang), 3.0], [0, 0, 0, 1]]),
+        np.array([[0.3, -1.2, 0.4, 7.0], [0.9, 0.1, -0.6, -2.5], [0.2, 0.8, 1.7, 0.25], [0, 0, 0, 1]]),
+        np.eye(4)]).astype(np.float32)
+    pos = rng.uniform(-2, 2, (len(worlds), 48, 3)).astype(np.float32)
+    nrm = rng.normal(size=(len(worlds), 48, 3)).astype(np.float32)
+    out_p, out_n, out_v = np.zeros_like(pos), np.zeros_like(nrm), np.zeros_like(nrm)
+    out_t, out_m = np.zeros((len(worlds), 16), np.float32), np.zeros((len(worlds), 16), np.float32)
+    for w, W in enumerate(worlds):
+        Wf = np.ascontiguousarray(W.reshape(-1))
+        for i in range(pos.shape[1]):
+            L.ref_matrix_apply(0, Wf.ctypes.data, pos[w, i].ctypes.data, out_p[w, i].ctypes.data)
+            L.ref_matrix_apply(3, Wf.ctypes.data, nrm[w, i].ctypes.data, out_n[w, i].ctypes.data)
+            L.ref_matrix_apply(1, Wf.ctypes.data, nrm[w, i].ctypes.data, out_v[w, i].ctypes.data)
+        L.ref_matrix_apply(2, Wf.ctypes.data, None, out_t[w].ctypes.data)
+        other = np.ascontiguousarray(worlds[(w + 1) % len(worlds)].reshape(-1))
+        L.ref_matrix_apply(4, Wf.ctypes.data, other.ctypes.data, out_m[w].ctypes.data)
+    tris = rng.uniform(-3, 3, (32, 3, 8)).astype(np.float32)
+    tris[5, 1, :3] = tris[5, 0, :3]      # zero area
+    tris[6, 2, :3] = tris[6, 1, :3]
+    centre = np.zeros((32, 5), np.float32)
+    for i in range(32):
+        L.ref_tri_centre(tris[i].ctypes.data, centre[i].ctypes.data)
+    np.savez_compressed(os.path.join(HERE, "scalars_r2.npz"), vec2_xy=xy, vec2_index=vec2, worlds=worlds, pos=pos, nrm=nrm,
+                        mul_point=out_p, normal_xf=out_n, mul_vec=out_v, transpose=out_t, mul=out_m, tris=tris, centre_area=centre)
+    print("vec2 index values over [0,1)^2:", np.unique(vec2[:256]), "edge rows:", vec2[256:].tolist())
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "r2":
+        pins_r2()
+    else:
+        main()

@@ -149,3 +149,55 @@ def test_corrupt_counts_fail_cleanly(tmp_path):
     path.write_bytes(good[:len(good) // 2])
     r = subprocess.run([_cli(), "-scene", str(tmp_path / "scene"), "-dump", str(tmp_path / "x.rtsc")], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "truncated" in (r.stdout + r.stderr)
+
+
+def test_hand_assembled_gem_bytes_against_reference_transforms(tmp_path):
+    """SURVEY 8(f1) against bytes this repository's writer (raytracer_amd/gem.py) never touched: the .gem file is packed here,
+    field by field, from the layout GEMModelLoader::load / loadMesh read (GEMLoader.h:218-365: magic 4058972161, isAnimated,
+    mesh count; per mesh: property count + (length, bytes) string pairs, vertex count + 44-byte GEMStaticVertex records
+    {position, normal, tangent, u, v}, index count + u32 indices), scene.json is literal text with the parser's corner cases
+    (exponent notation, true / false, numbers that pass through std::to_string's six decimals, GEMLoader.h:459-480), and the
+    expected world-space vertices are the COMPILED REFERENCE's Matrix::mulPoint / invert().transpose().mulVec().normalize()
+    outputs (tests/golden/scalars_r2.npz, SceneLoader.h:196-219), compared bit for bit."""
+    import struct
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scalars_r2.npz"))
+    W = g["worlds"][1]
+    pos, nrm, want_p, want_n = g["pos"][1], g["nrm"][1], g["mul_point"][1], g["normal_xf"][1]
+    rng = np.random.default_rng(17)
+    uv = rng.uniform(0, 1, (48, 2)).astype(np.float32)
+
+    def lstr(b):
+        return struct.pack("<i", len(b)) + b
+
+    def mesh(lo, hi, indices, props):
+        out = struct.pack("<I", len(props))
+        for k, v in props:
+            out += lstr(k) + lstr(v)
+        out += struct.pack("<I", hi - lo)
+        for i in range(lo, hi):   # GEMStaticVertex: position, normal, tangent, u, v = 11 floats
+            out += struct.pack("<11f", *pos[i], *nrm[i], 1.0, 0.0, 0.0, *uv[i])
+        out += struct.pack("<I", len(indices)) + struct.pack(f"<{len(indices)}I", *indices)
+        return out
+
+    idx0 = [int(i) for i in rng.permutation(24)]                       # 8 triangles over mesh 0's 24 vertices, shuffled
+    idx1 = [int(i) for i in rng.permutation(24)]                       # mesh 1: offset by mesh 0's INDEX count (SceneLoader.h:220)
+    blob = struct.pack("<III", 4058972161, 0, 2) + mesh(0, 24, idx0, [(b"name", b"first"), (b"note", b"")]) + mesh(24, 48, idx1, [])
+    d = tmp_path / "scene"; d.mkdir()
+    (d / "hand.gem").write_bytes(blob)
+    world = ", ".join("%.9e" % float(x) for x in W.reshape(-1))
+    (d / "scene.json").write_text('{\n  "width": 6.4e1, "height": 48,\n  "fov": 3.55E+1, "from": "0 1 5", "to": "0 0.5 0", "up": "0 1 0", "flipX": true,\n'
+                                  '  "instances": [\n    {"world": [' + world + '], "reflectance": "none.png", "filename": "hand.gem", "intIOR": 1.3333333333,\n'
+                                  '     "roughness": 2.5e-1, "bsdf": "plastic", "emission": "0 0 0", "unused": false}\n  ]\n}\n')
+    got, out = dump(d, tmp_path)
+    assert "number of triangle: 16" in out
+    exp = np.zeros((16, 3, 8), np.float32)
+    for t in range(16):
+        for k in range(3):
+            i = idx0[t * 3 + k] if t < 8 else 24 + idx1[(t - 8) * 3 + k]
+            exp[t, k] = np.concatenate([want_p[i], want_n[i], uv[i]])
+    assert got.verts.shape == exp.shape
+    assert np.array_equal(got.verts.view(np.uint32), exp.view(np.uint32))                      # positions, normals, uv: bit for bit
+    m, = got.materials
+    assert m.type == scenes.PLASTIC and m.roughness == np.float32(0.25)
+    assert m.int_ior == np.float32(float("%.6f" % 1.3333333333)) != np.float32(1.3333333333)    # "1.333333": std::to_string keeps six decimals
+    assert (got.width, got.height) == (64, 48) and got.cam_P[0] < 0                            # 6.4e1 -> 64; flipX: true -> "1"

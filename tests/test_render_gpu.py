@@ -537,3 +537,24 @@ def test_hostile_scene_renders_like_the_oracle():
     rt.clear(); rt.render(api.RADIOSITY, 2, 3, 0); rt.render(api.MLT, 1, 3, 2)
     assert rt.getSPP() == 3 and rt.film()[0].shape == (48, 48, 3)
     rt.close(); sc.close()
+
+
+def test_environment_map_tables_on_the_device():
+    """EnvironmentMap::build / SampleContinuous / sample / PDF (Lights.h:207-424) on the device against the oracle: the table
+    walk is additions, compares and one division, so SampleContinuous agrees bit for bit; sample() and PDF() end at
+    wi = (0, 1, 0), pdf = +inf on both sides (Vec2::operator[]'s int, pinned by tests/golden/scalars_r2.npz)."""
+    s = scenes.open_box(48, 48, "env")
+    o, sc = orc.OracleScene(s), api.Scene(s)
+    rng = np.random.default_rng(12)
+    u = np.concatenate([rng.uniform(0, 1, (6000, 3)), [[0.0, 0.0, 0], [0.99999994, 0.99999994, 0], [0.5, 0.99999994, 0], [0.99999994, 0.25, 0]]]).astype(np.float32)
+    gc, wc = sc.env_probe(1, u), o.env_probe(1, u)
+    assert np.array_equal(gc.view(np.uint32), wc.view(np.uint32))
+    gs, ws = sc.env_probe(0, u), o.env_probe(0, u)
+    assert np.array_equal(gs.view(np.uint32), ws.view(np.uint32)) and (gs[:6000, :3] == [0.0, 1.0, 0.0]).all() and np.isposinf(gs[:6000, 3]).all()
+    w = rng.normal(size=(2000, 3)); w /= np.linalg.norm(w, axis=1, keepdims=True)
+    gp, wp = sc.env_probe(2, w)[:, 0], o.env_probe(2, w)[:, 0]
+    assert np.isposinf(gp).all() and np.isposinf(wp).all()
+    plain = api.Scene(scenes.cornell(16, 16))
+    with pytest.raises(api.RtError, match="environment map"):
+        plain.env_probe(0, u[:4])
+    plain.close(); sc.close(); o.close()

@@ -90,6 +90,15 @@ def test_bench_line_with_two_ranks(scaling, steps, per_rank, total):
     assert 4.0 < b["config"]["rays_per_pixel_sample"] < 7.5
 
 
+def test_rccl_all_reduce_on_the_bound_film():
+    """backend "nccl" is RCCL on ROCm: initialise it once on the test box (one rank), reduce a film that the renderer wrote
+    through rt_film_bind, and check that the film and the SPP count come back unchanged -- so that the driver's multi-GPU run
+    is not the first time RCCL meets this code."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_one_rank.py"), str(_free_port())], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "rccl one-rank ok: backend nccl" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_bench_line_contract_one_gpu():
     """The one JSON line of `python bench.py` at N=1 carries every field the driver and the judge read (a reduced scene and
     one CPU sample keep it to seconds; the numbers themselves are not judged here)."""

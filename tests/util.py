@@ -8,7 +8,7 @@ from raytracer_amd import scenes
 from raytracer_amd.abi import HIT_DTYPE
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-GOLDEN_SCENES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not p.endswith("scalars.npz"))
+GOLDEN_SCENES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not os.path.basename(p).startswith("scalars"))
 
 
 def load_golden(name):
