@@ -327,7 +327,8 @@ __global__ __launch_bounds__(RT_BIN_BLOCK) void k_bin(RBuf R, Ctl* ctl, int cur,
 // test, Russian roulette, BSDF sample, throughput update, next ray.  RADIOSITY adds the VPL gather request of
 // pathTraceRadiosity (Renderer.h:931).
 #define RT_SHADE_BLOCK 512
-template <bool RADIOSITY>
+// ENV: the scene's light list holds an EnvironmentMap (its tabulated sampling costs 19 VGPRs; scenes without one run the lean instantiation)
+template <bool RADIOSITY, bool ENV>
 #ifndef RT_SHADE_OCC
 #define RT_SHADE_OCC 2   // blocks of 512 per CU the register budget is set for
 #endif
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_OCC) void k_shade(DScene S
                         sh_c = make_float4(cc.r, cc.g, cc.b, __uint_as_float(nfb));
                     }
                 }
-                else {   // EnvironmentMap::sample (Lights.h:385-399): tabulated draw, read through Vec2::operator[]'s int (env_sample_dir)
+                else if (ENV) {   // EnvironmentMap::sample (Lights.h:385-399): tabulated draw, read through Vec2::operator[]'s int (env_sample_dir)
                     float pdf;
                     f3 wi = env_sample_dir(S, r1, r2, pdf);
                     col3 emitted = bg_evaluate(S, wi);
@@ -1420,8 +1421,10 @@ static int render_path_like(rt_renderer* r, int mode, uint32_t batch, uint64_t s
         else if (r->lanes == 1) LAUNCHK(RT_KID_EXTEND, (k_extend<false, false, 1>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
         else LAUNCHK(RT_KID_EXTEND, (k_extend<false, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
         LAUNCH(k_bin, r->flat_blocks / 2, RT_BIN_BLOCK, R, r->ctl, cur, b == 0 ? 1 : 0);
-        if (radiosity) LAUNCHK(RT_KID_SHADE, k_shade<true>, r->flat_blocks / 2, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
-        else LAUNCHK(RT_KID_SHADE, k_shade<false>, r->flat_blocks / 2, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
+        if (radiosity && S.env_cond) LAUNCHK(RT_KID_SHADE, (k_shade<true, true>), r->flat_blocks / 2, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
+        else if (radiosity) LAUNCHK(RT_KID_SHADE, (k_shade<true, false>), r->flat_blocks / 2, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
+        else if (S.env_cond) LAUNCHK(RT_KID_SHADE, (k_shade<false, true>), r->flat_blocks / 2, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
+        else LAUNCHK(RT_KID_SHADE, (k_shade<false, false>), r->flat_blocks / 2, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
         if (r->count_enabled) LAUNCHK(RT_KID_CONNECT, k_connect<true>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
         else LAUNCHK(RT_KID_CONNECT, k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
         if (radiosity) {
@@ -1488,7 +1491,8 @@ static int render_mlt(rt_renderer* r, uint32_t chains, uint64_t seed, uint64_t f
         LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n, n);
         LAUNCHK(RT_KID_EXTEND, (k_extend<false, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
         LAUNCH(k_bin, r->flat_blocks / 2, RT_BIN_BLOCK, R, r->ctl, cur, b == 0 ? 1 : 0);
-        LAUNCHK(RT_KID_SHADE, k_shade<false>, r->flat_blocks / 2, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
+        if (S.env_cond) LAUNCHK(RT_KID_SHADE, (k_shade<false, true>), r->flat_blocks / 2, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
+        else LAUNCHK(RT_KID_SHADE, (k_shade<false, false>), r->flat_blocks / 2, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
         LAUNCHK(RT_KID_CONNECT, k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
     }
     LAUNCH(k_ctl_final, 1, 1, r->ctl);

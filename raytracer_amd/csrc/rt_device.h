@@ -298,10 +298,22 @@ __device__ bool rt_walk_exact(const DScene& S, f3 o, f3 dir, float maxT, HitRec&
 // reference's box rule (tentry <= texit && !(tentry > maxT)) plus a padded "entirely behind the origin" skip, any
 // order.  Skipping only uses the padded interval; whether a child is *entered* is always the reference's own
 // test on the reference's own box.
+// Slack of the conservative culls, as a fraction of the largest coordinate in play (scene extent, ray origin): a box is grown
+// by delta = RT_PAD_SCALE * M before the walk may skip it.  What the slack has to cover: an accepted
+// hit's point p = o + dir * t lies inside its triangle -- hence inside every box around it -- up to the rounding of the
+// plane equation, of p and of the barycentric test, together < 2^-19 M whatever the triangle's shape; expressing the box
+// planes in t adds 8 * 2^-24 M |1/dir|.  2^-17 M (128 ulp) is three times that bound.  Round 1 used 2^-14: for rays nearly
+// parallel to an axis the pad in t is delta * |1/dir|, and the eight-fold larger pad kept whole subtrees behind the origin
+// and beyond the best hit alive (+4.9 % Mrays/s on the bench scene from this constant and the per-axis any-hit pad below).
+#ifndef RT_PAD_SCALE
+#define RT_PAD_SCALE 7.62939453125e-06f   // 2^-17
+#endif
+// Any-hit walks test "entirely behind the origin" with the per-axis pad as well (3 adds + 2 mins per child more than round 1's
+// scalar delta * max |1/dir|, which let axis-parallel shadow rays walk everything behind them: k_connect -6 %).
 struct Walk {
     f3 o, dir, inv;
     f3 pad;        // closest hit
-    float maxT, padt;  // any hit
+    float maxT;        // any hit
     HitRec best;
     uint32_t cur, sp;
     uint32_t sx, sy, sz;   // 48 where 1/dir is negative on that axis, else 0: byte distance from a node's lo plane row to its hi row
@@ -309,10 +321,9 @@ struct Walk {
 };
 __device__ __forceinline__ void rt_walk_init(const DScene& S, Walk& w, f3 o, f3 dir, f3 inv, float maxT) {
     float scale = fmaxf(S.abs_max, fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))));
-    float delta = scale * 6.103515625e-05f;  // 2^-14: ~1000 ulp of the largest coordinate in play
+    float delta = scale * RT_PAD_SCALE;
     w.o = o; w.dir = dir; w.inv = inv;
     w.pad = mk3(delta * fabsf(inv.x), delta * fabsf(inv.y), delta * fabsf(inv.z));
-    w.padt = delta * fmaxf(fabsf(inv.x), fmaxf(fabsf(inv.y), fabsf(inv.z)));
     w.maxT = maxT;
     w.sx = inv.x < 0.0f ? 48u : 0u; w.sy = inv.y < 0.0f ? 48u : 0u; w.sz = inv.z < 0.0f ? 48u : 0u;
     w.cur = S.root_ref; w.sp = 0; w.occluded = false;
@@ -350,7 +361,7 @@ __device__ __forceinline__ bool rt_node_eval(const DScene& S, Walk& w, TravStack
         float texit = fminf(exx, fminf(exy, exz));                                                         \
         bool pass = (tentry <= texit);                                                                     \
         if (ANY) {                                                                                         \
-            pass = pass && !(tentry > w.maxT) && !((texit + w.padt) < 0.0f);                               \
+            pass = pass && !(tentry > w.maxT) && !(fminf(exx + w.pad.x, fminf(exy + w.pad.y, exz + w.pad.z)) < 0.0f); \
             KEY = pass ? tentry : RT_INF;                                                                  \
         } else {                                                                                           \
             float lo_ = fmaxf(enx - w.pad.x, fmaxf(eny - w.pad.y, enz - w.pad.z));                         \
@@ -601,13 +612,13 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
                     if (donor) { float key; give = st.get(--w.sp, key); }
                     // the ray and what is known about it so far travel by shuffle; non-thieves read themselves
                     const f3 o_ = rt_shfl_f3(w.o, from), d_ = rt_shfl_f3(w.dir, from), i_ = rt_shfl_f3(w.inv, from), p_ = rt_shfl_f3(w.pad, from);
-                    const float mt_ = rt_shfl_f(w.maxT, from), pt_ = rt_shfl_f(w.padt, from);
+                    const float mt_ = rt_shfl_f(w.maxT, from);
                     const float bt_ = rt_shfl_f(w.best.t, from), bu_ = rt_shfl_f(w.best.u, from), bv_ = rt_shfl_f(w.best.v, from);
                     const uint32_t br_ = (uint32_t)__shfl((int)w.best.rank, (int)from);
                     const uint32_t sx_ = (uint32_t)__shfl((int)w.sx, (int)from), sy_ = (uint32_t)__shfl((int)w.sy, (int)from), sz_ = (uint32_t)__shfl((int)w.sz, (int)from);
                     const uint32_t it_ = (uint32_t)__shfl((int)item, (int)from), cur_ = (uint32_t)__shfl((int)give, (int)from);
                     if (thief) {
-                        w.o = o_; w.dir = d_; w.inv = i_; w.pad = p_; w.maxT = mt_; w.padt = pt_;
+                        w.o = o_; w.dir = d_; w.inv = i_; w.pad = p_; w.maxT = mt_;
                         w.best.t = bt_; w.best.u = bu_; w.best.v = bv_; w.best.rank = br_;
                         w.sx = sx_; w.sy = sy_; w.sz = sz_; w.cur = cur_; w.sp = 0; w.occluded = false;
                         item = it_; busy = true; visible = true;

@@ -8,7 +8,6 @@
 #include <chrono>
 #include <fstream>
 #include <iostream>
-#include <unordered_map>
 
 #include "gem.hpp"
 
@@ -19,36 +18,33 @@ int main(int argc, char* argv[]) {
     int type = 0, width = 1024, height = 1024, perCall = 1, vpls = 0, png = 0, filter = RT_FILTER_BOX;
     std::string dump, keys, aov;
     unsigned long long seed = 1;
-    std::unordered_map<std::string, std::string> args;
-    for (int i = 1; i < argc; ++i) {
-        std::string arg = argv[i];
-        if (!arg.empty() && arg[0] == '-') {
-            if (i + 1 < argc) args[arg] = argv[++i];
-            else std::cerr << "Error: Missing value for argument '" << arg << "'\n";
-        } else std::cerr << "Warning: Ignoring unexpected argument '" << arg << "'\n";
-    }
     try {
-        for (const auto& pair : args) {
-            if (pair.first == "-scene") sceneName = pair.second;
-            else if (pair.first == "-outputFilename") filename = pair.second;
-            else if (pair.first == "-SPP") SPP = (unsigned int)std::stoi(pair.second);
-            else if (pair.first == "-type") type = std::stoi(pair.second);
-            else if (pair.first == "-width") width = std::stoi(pair.second);
-            else if (pair.first == "-height") height = std::stoi(pair.second);
-            else if (pair.first == "-seed") seed = std::stoull(pair.second);
-            else if (pair.first == "-sppPerCall") perCall = std::stoi(pair.second);
-            else if (pair.first == "-vpls") vpls = std::stoi(pair.second);
-            else if (pair.first == "-keys") keys = pair.second;
-            else if (pair.first == "-filter") {
-                if (pair.second == "box") filter = RT_FILTER_BOX;
-                else if (pair.second == "gaussian") filter = RT_FILTER_GAUSSIAN;
-                else if (pair.second == "mitchell") filter = RT_FILTER_MITCHELL;
+        // name / value pairs, later ones win; a name without a value or a bare word is reported and skipped
+        for (int i = 1; i < argc; i++) {
+            const std::string name = argv[i];
+            if (name.size() < 2 || name[0] != '-') { std::cerr << "rtamd_cli: skipping stray word '" << name << "'\n"; continue; }
+            if (i + 1 >= argc) { std::cerr << "rtamd_cli: option " << name << " needs a value\n"; break; }
+            const std::string value = argv[++i];
+            if (name == "-scene") sceneName = value;
+            else if (name == "-outputFilename") filename = value;
+            else if (name == "-SPP") SPP = (unsigned int)std::stoi(value);
+            else if (name == "-type") type = std::stoi(value);
+            else if (name == "-width") width = std::stoi(value);
+            else if (name == "-height") height = std::stoi(value);
+            else if (name == "-seed") seed = std::stoull(value);
+            else if (name == "-sppPerCall") perCall = std::stoi(value);
+            else if (name == "-vpls") vpls = std::stoi(value);
+            else if (name == "-keys") keys = value;
+            else if (name == "-filter") {
+                if (value == "box") filter = RT_FILTER_BOX;
+                else if (value == "gaussian") filter = RT_FILTER_GAUSSIAN;
+                else if (value == "mitchell") filter = RT_FILTER_MITCHELL;
                 else throw std::runtime_error("-filter: box, gaussian or mitchell");
             }
-            else if (pair.first == "-png") png = std::stoi(pair.second);
-            else if (pair.first == "-dump") dump = pair.second;
-            else if (pair.first == "-aov") aov = pair.second;
-            else std::cerr << "Warning: unknown argument '" << pair.first << "'\n";
+            else if (name == "-png") png = std::stoi(value);
+            else if (name == "-dump") dump = value;
+            else if (name == "-aov") aov = value;
+            else std::cerr << "rtamd_cli: unknown option " << name << "\n";
         }
         if (perCall < 1) perCall = 1;
         auto press = [](char key) {   // Main.cpp:87-116

@@ -30,14 +30,17 @@ for name, make, spp in JOBS:
         continue
     s = make()
     o = orc.OracleScene(s)
-    film = np.zeros((s.height, s.width, 3), np.float64)
+    part_file = "/tmp/" + name + ".partial.npz"     # resumable: the sum so far and how many samples it holds
+    film, done = np.zeros((s.height, s.width, 3), np.float64), 0
+    if os.path.exists(part_file):
+        z = np.load(part_file); film, done = z["film"], int(z["done"])
     t = time.time()
-    done = 0
     while done < spp:   # in slices: fp32 film sums stay short, progress is visible
         k = min(1024, spp - done)
         part, st = o.render(mode=0, spp=k, seed=987654321, first_sample=done, threads=threads)
         film += part
         done += k
+        np.savez(part_file + ".tmp.npz", film=film, done=done); os.replace(part_file + ".tmp.npz", part_file)
         print(name, done, "%.0fs" % (time.time() - t), flush=True)
     assert np.isfinite(film).all()
     np.save(out, (film / spp).astype(np.float32))

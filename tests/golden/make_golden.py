@@ -128,8 +128,29 @@ def pins_r2():
     print("vec2 index values over [0,1)^2:", np.unique(vec2[:256]), "edge rows:", vec2[256:].tolist())
 
 
+def survey_digest():
+    """SURVEY 8(d)'s fixed Cornell ray set (3 x 2^20, seed 1) through the compiled reference: a digest of its answers, so the
+    GPU test's primary pin is a committed fixture and not the untracked _ref binary.   python tests/golden/make_golden.py digest"""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import hits_digest
+    s = scenes.cornell(1024, 1024)
+    r = orc.RefScene(s)
+    n = 1 << 20
+    rays = np.concatenate([scenes.primary_rays(s, n, 1), scenes.bounce_rays(s, n, 1)])
+    segs = scenes.shadow_segments(s, n, 1)
+    hits, vis = r.traverse(rays), r.visible(segs)
+    out = {"scene": "scenes.cornell(1024, 1024)", "rays": "primary_rays(s, 2^20, 1) ++ bounce_rays(s, 2^20, 1)", "segments": "shadow_segments(s, 2^20, 1)",
+           "sha256": hits_digest(hits, vis), "hits": int((hits["t"] < 3e38).sum()), "visible": int(vis.sum()),
+           "source": "oracle/_ref/libref_geom.so (the reference's Geometry.h compiled by oracle/Makefile)"}
+    json.dump(out, open(os.path.join(HERE, "cornell_survey_digest.json"), "w"), indent=1)
+    print(out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "r2":
         pins_r2()
+    elif len(sys.argv) > 1 and sys.argv[1] == "digest":
+        survey_digest()
     else:
         main()

@@ -46,14 +46,22 @@ def test_against_oracle(make):
 
 def test_cornell_fixed_ray_set_of_the_survey():
     """SURVEY.md 8(d), BASELINE config 2: Cornell box at 1024x1024, 2^20 primary rays + 2^20 cosine-bounce rays + 2^20 NEE
-    segments from seed 1, every one bit-exact (the compiled reference answers when its build travelled with the tree)."""
+    segments from seed 1, every one bit-exact.  Primary pin: the committed digest of the compiled reference's answers
+    (tests/golden/cornell_survey_digest.json, made by tests/golden/make_golden.py digest); the per-ray comparison against the
+    oracle (or the reference build, when it travelled with the tree) says where a mismatch would be."""
+    import json
+    from util import GOLDEN, hits_digest
     s = scenes.cornell(1024, 1024)
     ref = orc.RefScene(s) if orc.have_ref() else orc.OracleScene(s)
     sc = api.Scene(s)
     n = 1 << 20
     rays = np.concatenate([scenes.primary_rays(s, n, 1), scenes.bounce_rays(s, n, 1)])
+    pin = json.load(open(f"{GOLDEN}/cornell_survey_digest.json"))
+    got0 = sc.traverse(rays, 0)
+    assert hits_digest(got0, sc.visible(scenes.shadow_segments(s, n, 1), 0)) == pin["sha256"]
+    assert int((got0["t"] < 3e38).sum()) == pin["hits"]
     want = ref.traverse(rays)
-    assert_hits_bitexact(sc.traverse(rays, 0), want, "cornell 2^21 rays, wide")
+    assert_hits_bitexact(got0, want, "cornell 2^21 rays, wide")
     assert_hits_bitexact(sc.traverse(rays, 1), want, "cornell 2^21 rays, reference order")
     segs = scenes.shadow_segments(s, n, 1)
     vis = ref.visible(segs)
@@ -233,4 +241,45 @@ def test_launches_on_two_streams_share_the_scene_scratch_safely():
     for t in th: t.join()
     assert_hits_bitexact(res["a"], want_a, "thread a")
     assert_hits_bitexact(res["b"], want_b, "thread b")
+    sc.close()
+
+
+def test_cull_slack_holds_for_far_origins_grazing_and_near_axis_rays():
+    """The ordered walk may skip a box only through a slack of 2^-17 of the largest coordinate in play (rt_device.h,
+    RT_PAD_SCALE).  Rays chosen to strain it: origins 10^2..10^5 scene sizes away aimed at surface points
+    (the slack scales with |o|, the hit point's rounding too), directions within 10^-3..10^-7 of an axis (|1/dir| up to 10^7: the
+    pad in t is at its largest), rays grazing the tessellated fixtures within 10^-4 rad of their tangent planes, and shadow
+    segments of the same kinds.  The reference-order walk (no culling at all, upstream's own sequence) must agree bit for bit."""
+    s = scenes.interior("bathroom", 0.5, 64, 36)
+    sc = api.Scene(s)
+    rng = np.random.default_rng(77)
+    n = 400_000
+    pos, nn = scenes.surface_points(s, 3 * n, rng)
+    # far origins
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dist = 10.0 ** rng.uniform(2, 6, (n, 1))
+    far = np.concatenate([pos[:n] - d * dist, d * 10.0 ** rng.uniform(-3, 3, (n, 1))], 1)
+    # near-axis directions through surface points
+    ax = rng.integers(0, 3, n)
+    da = rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-7, -3, (n, 1))
+    da[np.arange(n), ax] = rng.choice([-1.0, 1.0], n)
+    near_axis = np.concatenate([pos[n:2 * n] - da * rng.uniform(0.1, 5, (n, 1)), da], 1)
+    # grazing: direction in the tangent plane, tilted by 1e-6..1e-4 towards the surface
+    t = np.cross(nn[2 * n:], rng.normal(size=(n, 3))); t /= np.maximum(np.linalg.norm(t, axis=1, keepdims=True), 1e-20)
+    g = t - nn[2 * n:] * 10.0 ** rng.uniform(-6, -4, (n, 1))
+    graze = np.concatenate([pos[2 * n:] - g * rng.uniform(0.01, 3, (n, 1)), g], 1)
+    rays = np.concatenate([far, near_axis, graze]).astype(np.float32)
+    wide, ref = sc.traverse(rays, 0), sc.traverse(rays, 1)
+    assert_hits_bitexact(wide, ref, "strained rays, wide vs reference order", nan_payload_free=True)
+    assert 0.3 < (ref["t"] < 3e38).mean() < 1.0
+    segs = np.concatenate([rays[:, :3], rays[:, :3] + rays[:, 3:] * rng.uniform(0.5, 2.0, (len(rays), 1)).astype(np.float32) *
+                           np.where(ref["t"] < 3e38, ref["t"], 1.0)[:, None]], 1).astype(np.float32)   # ends around the first hit
+    v0, v1 = sc.visible(segs, 0), sc.visible(segs, 1)
+    assert np.array_equal(v0, v1) and 0.05 < v0.mean() < 0.95
+    if orc.have_ref():      # and against the compiled reference itself on a sample
+        r = orc.RefScene(s)
+        k = rng.choice(len(rays), 60_000, replace=False)
+        assert_hits_bitexact(wide[k], r.traverse(rays[k]), "strained rays vs compiled reference", nan_payload_free=True)
+        assert np.array_equal(v0[k], r.visible(segs[k]))
+        r.close()
     sc.close()

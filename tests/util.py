@@ -57,3 +57,17 @@ def axis_rays(s, n, seed=11):
     two = rng.uniform(0, 1, n) < 0.4
     d[two, (ax[two] + 1) % 3] = rng.uniform(-1, 1, two.sum()).astype(np.float32)
     return np.concatenate([o, d], 1).astype(np.float32)
+
+
+def hits_digest(hits, vis=None):
+    """sha256 over hit/miss, triangle ID, t, alpha, beta, gamma (hits only; a miss has no defined ID) and a visibility array."""
+    import hashlib
+    h = hashlib.sha256()
+    m = hits["t"] < 3e38
+    h.update(np.packbits(m).tobytes())
+    h.update(np.ascontiguousarray(hits["ID"][m]).tobytes())
+    for k in ("t", "alpha", "beta", "gamma"):
+        h.update(np.ascontiguousarray(hits[k][m]).tobytes())
+    if vis is not None:
+        h.update(np.packbits(np.asarray(vis, np.uint8)).tobytes())
+    return h.hexdigest()

@@ -73,6 +73,6 @@ def derive(kname, tag):
 
 derive("k_extend<false, false, 0>", "k_extend")
 derive("k_connect<false>", "k_connect")
-derive("k_shade<false>", "k_shade")
+derive("k_shade<false, false>", "k_shade")
 derive("k_bin", "k_bin")
 print(json.dumps(res, indent=1))
