@@ -111,12 +111,13 @@ int rt_device_set(int device);
 
 /* --- Scene::init + Scene::build (Scene.h:150, :92): Triangle::init precompute, reference-topology
  * binned-SAH BVH (Geometry.h:310-438), light list (Scene.h:107-116), flatten + upload.
- * The binned-SAH build of the binary tree (BVHNode::build, Geometry.h:391-438 -- 85 % of scene set-up time when it
- * runs on the host) runs on the GPU, level by level; the tree, the leaf order and every traversal result are the
- * same as with the host build (tests/test_bvh_build_gpu.py), which rt_scene_create_ex can still ask for. */
+ * The binned-SAH build of the binary tree (BVHNode::build, Geometry.h:391-438), Triangle::init's records, the
+ * reference-topology node array and the 4-wide collapse all run on the GPU, level by level; the tree, the leaf order,
+ * the wide node array and every traversal result are the same as with the host build (tests/test_bvh_build_gpu.py),
+ * which rt_scene_create_ex can still ask for. */
 int rt_scene_create(const rt_scene_desc* desc, rt_scene** out);
 #define RT_SCENE_BUILD_DEVICE 1u   /* the default of rt_scene_create */
-#define RT_SCENE_BUILD_HOST 2u     /* single-threaded host build of the binary tree */
+#define RT_SCENE_BUILD_HOST 2u     /* everything on the host (single-threaded binary tree) */
 int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_scene** out);   /* flags: one of the two, or 0 = default */
 void rt_scene_destroy(rt_scene* scene);
 /* --- Camera::init + Camera::updateView (Scene.h:26, :37) */
@@ -124,6 +125,9 @@ int rt_scene_set_camera(rt_scene* scene, const rt_camera* cam);
 int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
 /* DFS leaf order of the reference tree (triangle indices), for structural parity checks. */
 int rt_scene_leaf_order(const rt_scene* scene, uint32_t* out_n_tris);
+/* The flattened 4-wide tree (wide_nodes x 128 B: lox[4] loy[4] loz[4] hix[4] hiy[4] hiz[4] child[4] pad[4]) as it sits in
+ * device memory, for structural checks (device-side build == host build). */
+int rt_scene_debug_wide_nodes(rt_scene* scene, void* out, size_t max_nodes);
 /* Host-only structure query: runs the same builder without touching a device (leaf_order/info may be NULL).
  * Not a compute path: nothing can be traversed or rendered without a GPU. */
 int rt_host_build_info(const rt_scene_desc* desc, uint32_t* leaf_order, rt_scene_info* info);

@@ -56,7 +56,7 @@ SYMBOLS = [
     "rt_renderer_create", "rt_renderer_destroy", "rt_render", "rt_film_clear", "rt_film_spp", "rt_film_read", "rt_film_bind",
     "rt_film_set_spp", "rt_vpl_trace", "rt_vpl_count", "rt_render_counters", "rt_renderer_sync", "rt_film_save_hdr",
     "rt_film_tonemap", "rt_profile_enable", "rt_profile_read", "rt_debug_bsdf_sample", "rt_debug_bsdf_eval", "rt_debug_rng", "rt_matrix_invert", "rt_scene_create_ex",
-    "rt_renderer_set_filter", "rt_render_aov", "rt_intersect_closest_noalloc", "rt_renderer_set_streams", "rt_debug_env",
+    "rt_renderer_set_filter", "rt_render_aov", "rt_intersect_closest_noalloc", "rt_renderer_set_streams", "rt_debug_env", "rt_scene_debug_wide_nodes",
 ]
 
 
@@ -89,6 +89,7 @@ def lib():
         _sig(L, "rt_scene_set_camera", [vp, C.POINTER(Camera)])
         _sig(L, "rt_scene_get_info", [vp, C.POINTER(SceneInfo)])
         _sig(L, "rt_scene_leaf_order", [vp, vp])
+        _sig(L, "rt_scene_debug_wide_nodes", [vp, vp, sz])
         _sig(L, "rt_host_build_info", [C.POINTER(SceneDesc), vp, C.POINTER(SceneInfo)])
         _sig(L, "rt_intersect_closest", [vp, vp, sz, vp, i32])
         _sig(L, "rt_intersect_closest_dev", [vp, vp, sz, vp, i32, vp])
@@ -190,6 +191,13 @@ class Scene:
         o = np.zeros(self.ntris, np.uint32)
         _check(self.L.rt_scene_leaf_order(self.h, o.ctypes.data), "rt_scene_leaf_order")
         return o
+
+    def wide_nodes(self):
+        """The 4-wide tree from device memory: structured array of 128-B nodes."""
+        n = self.info()["wide_nodes"]
+        out = np.zeros(n, np.dtype([("box", np.float32, (6, 4)), ("child", np.uint32, 4), ("pad", np.uint32, 4)]))
+        _check(self.L.rt_scene_debug_wide_nodes(self.h, out.ctypes.data, n), "rt_scene_debug_wide_nodes")
+        return out
 
     # Scene::traverse (Scene.h:118)
     def traverse(self, rays, mode=0):

@@ -22,6 +22,8 @@
 #include <vector>
 
 #include "scene_build.h"
+#include <string.h>
+#include <utility>
 
 namespace {
 
@@ -263,6 +265,169 @@ __global__ void k_children(uint32_t n_pending, const uint32_t* __restrict__ pend
     nodes[ni] = nd;
 }
 
+// ================================================================================================ after the tree
+// Everything else that is per triangle or per node, on the arrays the build left in device memory.
+
+__device__ __forceinline__ float d_dot(const float* a, const float* b) { return ((a[0] * b[0]) + (a[1] * b[1]) + (a[2] * b[2])); }
+__device__ __forceinline__ void d_cross(const float* a, const float* b, float* o) {
+    o[0] = (a[1] * b[2]) - (a[2] * b[1]); o[1] = (a[2] * b[0]) - (a[0] * b[2]); o[2] = (a[0] * b[1]) - (a[1] * b[0]);
+}
+// Triangle::init (Geometry.h:66-82) into the 64-B records, one thread per DFS rank; scene bounds (Scene::init, Scene.h:152-158)
+// and the largest |coordinate| by integer atomics on order-preserving keys.  Same expressions as scene_build.cpp's host loop.
+__global__ void k_records(uint32_t n, const float* __restrict__ verts, const uint32_t* __restrict__ tri_mat, const uint32_t* __restrict__ order,
+                          DTri* __restrict__ tris, DTriShade* __restrict__ shade, uint32_t* bounds_keys /* lo xyz, hi xyz, amax */) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t lo[3] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu }, hi[3] = { 0u, 0u, 0u }, am = 0u;
+    if (r < n) {
+        const uint32_t t = order[r];
+        const float* f = verts + (size_t)t * 24;
+        float p0[3] = { f[0], f[1], f[2] }, p1[3] = { f[8], f[9], f[10] }, p2[3] = { f[16], f[17], f[18] };
+        float e1[3] = { p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2] }, e2[3] = { p0[0] - p2[0], p0[1] - p2[1], p0[2] - p2[2] };
+        float c[3]; d_cross(e1, e2, c);
+        float l = 1.0f / sqrtf((c[0] * c[0]) + (c[1] * c[1]) + (c[2] * c[2]));
+        float nn[3] = { c[0] * l, c[1] * l, c[2] * l };
+        DTri o;
+        for (int k = 0; k < 3; k++) { o.v0[k] = p0[k]; o.v1[k] = p1[k]; o.v2[k] = p2[k]; o.n[k] = nn[k]; }
+        o.d = d_dot(nn, p0);
+        o.inv_area = 1.0f / d_dot(c, nn);
+        o.orig_id = t;
+        float n0[3] = { f[3], f[4], f[5] };
+        const bool flip = !(d_dot(n0, nn) > 0);   // gNormal = n * (Dot(v0.normal, n) > 0 ? 1 : -1)
+        o.mat_gsign = tri_mat[t] | (flip ? 0x80000000u : 0u);
+        tris[r] = o;
+        DTriShade sh;
+        for (int k = 0; k < 3; k++) { sh.n0[k] = f[3 + k]; sh.n1[k] = f[11 + k]; sh.n2[k] = f[19 + k]; }
+        sh.uv[0] = f[6]; sh.uv[1] = f[7]; sh.uv[2] = f[14]; sh.uv[3] = f[15]; sh.uv[4] = f[22]; sh.uv[5] = f[23];
+        sh.area = sqrtf((c[0] * c[0]) + (c[1] * c[1]) + (c[2] * c[2])) * 0.5f;
+        shade[r] = sh;
+        for (int k = 0; k < 3; k++) {
+            lo[k] = fkey(fminf(p0[k], fminf(p1[k], p2[k]))); hi[k] = fkey(fmaxf(p0[k], fmaxf(p1[k], p2[k])));
+            am = max(am, __float_as_uint(fmaxf(fabsf(p0[k]), fmaxf(fabsf(p1[k]), fabsf(p2[k])))));   // non-negative floats order like their bits
+        }
+    }
+    for (int k = 0; k < 3; k++) { lo[k] = wave_min(lo[k]); hi[k] = wave_max(hi[k]); }
+    am = wave_max(am);
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 3; k++) { atomicMin(bounds_keys + k, lo[k]); atomicMax(bounds_keys + 3 + k, hi[k]); }
+        atomicMax(bounds_keys + 6, am);
+    }
+}
+// reference-topology nodes for the validation / fallback walk + the tree statistics rt_scene_info reports
+__global__ void k_nodes2(uint32_t n_nodes, const GNode* __restrict__ nodes, DNode2* __restrict__ out, uint32_t* stats /* max depth, leaves, max leaf */) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const GNode s = nodes[i];
+    DNode2 o;
+    for (int k = 0; k < 3; k++) { o.lo[k] = s.lo[k]; o.hi[k] = s.hi[k]; }
+    o.left = s.left; o.right = s.right;
+    const bool leaf = s.left < 0;
+    o.first = leaf ? (int32_t)s.begin : 0; o.count = leaf ? (int32_t)s.count : 0; o.pad0 = o.pad1 = 0;
+    out[i] = o;
+    atomicMax(stats + 0, s.depth);
+    if (leaf) { atomicAdd(stats + 1, 1u); atomicMax(stats + 2, s.count); }
+}
+
+// ---- 4-wide collapse, one level per launch: scene_build.cpp's Collapser (same slots, same greedy opening by largest box area,
+// same level-by-level numbering), one thread per wide node of the level.
+struct DSlot { float lo[3], hi[3]; int32_t bnode; uint32_t first, count; };
+struct DWork { int32_t bnode; float lo[3], hi[3]; uint32_t first, count; };
+__device__ __forceinline__ bool d_single(const GNode* nodes, int32_t i) { return nodes[i].left < 0 && nodes[i].count <= 1u; }
+__device__ __forceinline__ float d_area(const float* lo, const float* hi) {
+    float sx = hi[0] - lo[0], sy = hi[1] - lo[1], sz = hi[2] - lo[2];
+    return ((sx * sy) + (sy * sz) + (sx * sz)) * 2.0f;
+}
+__device__ inline DSlot d_make_slot(const GNode* __restrict__ nodes, int32_t child, const float* plo, const float* phi) {
+    const GNode c = nodes[child];
+    DSlot s; s.bnode = -1; s.first = c.begin; s.count = c.left < 0 ? c.count : 0u;
+    if (c.left < 0) {
+        const bool own = c.count >= 2u;
+        for (int k = 0; k < 3; k++) { s.lo[k] = own ? c.lo[k] : plo[k]; s.hi[k] = own ? c.hi[k] : phi[k]; }
+        return s;
+    }
+    for (int k = 0; k < 3; k++) { s.lo[k] = c.lo[k]; s.hi[k] = c.hi[k]; }
+    if (d_single(nodes, c.left) && d_single(nodes, c.right)) { s.first = nodes[c.left].begin; s.count = nodes[c.left].count + nodes[c.right].count; return s; }
+    s.bnode = child; s.count = 0u;
+    return s;
+}
+__device__ inline int d_gather(const GNode* __restrict__ nodes, const DWork& w, DSlot* slots) {
+    int ns = 0;
+    if (w.bnode < 0) {
+        const uint32_t parts = min(4u, (w.count + RT_LEAF_MAX - 1u) / RT_LEAF_MAX);
+        for (uint32_t p = 0; p < parts; p++) {
+            const uint32_t b = (uint32_t)((unsigned long long)w.count * p / parts), e = (uint32_t)((unsigned long long)w.count * (p + 1) / parts);
+            DSlot& s = slots[ns++];
+            for (int k = 0; k < 3; k++) { s.lo[k] = w.lo[k]; s.hi[k] = w.hi[k]; }
+            s.bnode = -1; s.first = w.first + b; s.count = e - b;
+        }
+        return ns;
+    }
+    const GNode b = nodes[w.bnode];
+    slots[ns++] = d_make_slot(nodes, b.left, b.lo, b.hi);
+    slots[ns++] = d_make_slot(nodes, b.right, b.lo, b.hi);
+    while (ns < 4) {
+        int pick = -1; float best = -1.0f;
+        for (int i = 0; i < ns; i++)
+            if (slots[i].bnode >= 0) { float a = d_area(slots[i].lo, slots[i].hi); if (a > best) { best = a; pick = i; } }
+        if (pick < 0) break;
+        const GNode e = nodes[slots[pick].bnode];
+        const DSlot l = d_make_slot(nodes, e.left, e.lo, e.hi), r = d_make_slot(nodes, e.right, e.lo, e.hi);
+        for (int i = ns; i > pick + 1; i--) slots[i] = slots[i - 1];
+        slots[pick] = l; slots[pick + 1] = r; ns++;
+    }
+    return ns;
+}
+__device__ __forceinline__ bool d_slot_is_node(const DSlot& s) { return s.bnode >= 0 || s.count > RT_LEAF_MAX; }
+// pass 1: how many children of each wide node become wide nodes of the next level
+__global__ void k_collapse_count(uint32_t n_items, const GNode* __restrict__ nodes, const DWork* __restrict__ items, uint32_t* __restrict__ counts) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_items) return;
+    if (i == n_items) { counts[i] = 0u; return; }   // the scan's extra entry: its exclusive sum is the level's total
+    DSlot slots[4];
+    const int ns = d_gather(nodes, items[i], slots);
+    uint32_t c = 0;
+    for (int k = 0; k < ns; k++) c += d_slot_is_node(slots[k]) ? 1u : 0u;
+    counts[i] = c;
+}
+// pass 2: write the level's nodes (children numbered from next_base in (parent, slot) order) and the next level's work items
+__global__ void k_collapse_emit(uint32_t n_items, uint32_t level_base, uint32_t next_base, const GNode* __restrict__ nodes, const DWork* __restrict__ items,
+                                const uint32_t* __restrict__ scan, DNode4* __restrict__ out, DWork* __restrict__ next_items) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    DSlot slots[4];
+    const int ns = d_gather(nodes, items[i], slots);
+    DNode4 n;
+    const float qnan = __uint_as_float(0x7FC00000u);
+    for (int k = 0; k < 4; k++) { n.child[k] = RT_REF_EMPTY; n.pad[k] = 0u; n.lox[k] = n.loy[k] = n.loz[k] = n.hix[k] = n.hiy[k] = n.hiz[k] = qnan; }
+    uint32_t slot_of_next = scan[i];
+    for (int k = 0; k < ns; k++) {
+        const DSlot& s = slots[k];
+        uint32_t ref;
+        if (d_slot_is_node(s)) {
+            DWork w; w.bnode = s.bnode; w.first = s.bnode >= 0 ? 0u : s.first; w.count = s.bnode >= 0 ? 0u : s.count;
+            for (int a = 0; a < 3; a++) { w.lo[a] = s.lo[a]; w.hi[a] = s.hi[a]; }
+            next_items[slot_of_next] = w;
+            ref = next_base + slot_of_next++;
+        } else ref = RT_REF_LEAF | ((s.count - 1u) << 27) | s.first;
+        n.lox[k] = s.lo[0]; n.loy[k] = s.lo[1]; n.loz[k] = s.lo[2]; n.hix[k] = s.hi[0]; n.hiy[k] = s.hi[1]; n.hiz[k] = s.hi[2];
+        n.child[k] = ref;
+    }
+    out[level_base + i] = n;
+}
+// entries a walk can have waiting below a wide node: its other children plus the worst of what a child needs; levels last to first
+__global__ void k_stack_need(uint32_t level_base, uint32_t n_items, const DNode4* __restrict__ nodes, uint32_t* __restrict__ need) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    const DNode4& n = nodes[level_base + i];
+    uint32_t used = 0, worst = 0;
+    for (int k = 0; k < 4; k++) {
+        const uint32_t ref = n.child[k];
+        if (ref == RT_REF_EMPTY) continue;
+        used++;
+        if (!(ref & RT_REF_LEAF)) worst = max(worst, need[ref]);
+    }
+    need[level_base + i] = (used ? used - 1u : 0u) + worst;
+}
+
 struct DevMem {
     std::vector<void*> ptrs;
     ~DevMem() { for (void* p : ptrs) (void)hipFree(p); }
@@ -271,65 +436,138 @@ struct DevMem {
 
 }  // namespace
 
-bool device_bvh2_build(const float* h_verts, uint32_t n, Bvh2& out, std::string& err) {
-    out.nodes.clear(); out.order.clear();
-    if (n == 0) return true;
+// The binary tree level by level (see the top of this file), then -- still on the device -- the triangle records in leaf
+// order, the reference-topology node array, the 4-wide collapse and its stack bound.  Only the leaf order (4 B per triangle),
+// a few counters per level and the scene statistics come back to the host.
+int device_scene_build(const rt_scene_desc& d, HostScene& hs, DeviceGeometry& out, std::string& err_) {
+    std::string& err = err_;
+    const uint32_t n = d.n_tris;
+    if (n < 2) return 2;   // nothing to build in parallel; the host's special cases (empty scene, single-triangle root) apply
     auto t0 = std::chrono::steady_clock::now();
+#define BB_CHECK0(call)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess) { err = std::string("bvh_build: ") + #call + ": " + hipGetErrorString(e_); return 0; } \
+    } while (0)
     uint32_t levels = 0;
     DevMem mem;
     float* verts; uint32_t *idx[2], *start_mark, *seg, *flags, *scan, *acc, *pending[2], *counters; int32_t* node_at_start; GNode* nodes; Split* splits;
     const size_t max_nodes = (size_t)2 * n + 1, max_pending = (size_t)n / 2 + 1;
-    BB_CHECK(mem.alloc(&verts, (size_t)n * 24)); BB_CHECK(mem.alloc(&idx[0], n)); BB_CHECK(mem.alloc(&idx[1], n));
-    BB_CHECK(mem.alloc(&start_mark, n)); BB_CHECK(mem.alloc(&seg, n)); BB_CHECK(mem.alloc(&flags, (size_t)n + 1)); BB_CHECK(mem.alloc(&scan, (size_t)n + 1));
-    BB_CHECK(mem.alloc(&node_at_start, n)); BB_CHECK(mem.alloc(&nodes, max_nodes)); BB_CHECK(mem.alloc(&splits, max_pending));
-    BB_CHECK(mem.alloc(&pending[0], max_pending)); BB_CHECK(mem.alloc(&pending[1], max_pending)); BB_CHECK(mem.alloc(&counters, 2));
-    BB_CHECK(mem.alloc(&acc, max_pending * ACC_WORDS));
+    BB_CHECK0(mem.alloc(&verts, (size_t)n * 24)); BB_CHECK0(mem.alloc(&idx[0], n)); BB_CHECK0(mem.alloc(&idx[1], n));
+    BB_CHECK0(mem.alloc(&start_mark, n)); BB_CHECK0(mem.alloc(&seg, n)); BB_CHECK0(mem.alloc(&flags, (size_t)n + 1)); BB_CHECK0(mem.alloc(&scan, (size_t)n + 1));
+    BB_CHECK0(mem.alloc(&node_at_start, n)); BB_CHECK0(mem.alloc(&nodes, max_nodes)); BB_CHECK0(mem.alloc(&splits, max_pending));
+    BB_CHECK0(mem.alloc(&pending[0], max_pending)); BB_CHECK0(mem.alloc(&pending[1], max_pending)); BB_CHECK0(mem.alloc(&counters, 2));
+    BB_CHECK0(mem.alloc(&acc, max_pending * ACC_WORDS));
     size_t tmp_a = 0, tmp_b = 0;
-    BB_CHECK(hipcub::DeviceScan::InclusiveScan(nullptr, tmp_a, start_mark, seg, hipcub::Max(), (int)n));
-    BB_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_b, flags, scan, (int)n + 1));
+    BB_CHECK0(hipcub::DeviceScan::InclusiveScan(nullptr, tmp_a, start_mark, seg, hipcub::Max(), (int)n));
+    BB_CHECK0(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_b, flags, scan, (int)n + 1));
     void* tmp; size_t tmp_bytes = std::max(tmp_a, tmp_b);
-    BB_CHECK(mem.alloc((char**)&tmp, tmp_bytes));
-    BB_CHECK(hipMemcpy(verts, h_verts, sizeof(float) * (size_t)n * 24, hipMemcpyHostToDevice));
-    if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "device bvh2: alloc + upload %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    BB_CHECK0(mem.alloc((char**)&tmp, tmp_bytes));
+    BB_CHECK0(hipMemcpy(verts, d.verts, sizeof(float) * (size_t)n * 24, hipMemcpyHostToDevice));
+    if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "device build: alloc + upload %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     const unsigned T = 256, gn = (n + T - 1) / T;
     hipLaunchKernelGGL(k_init, dim3(gn), dim3(T), 0, 0, n, idx[0], start_mark, node_at_start, nodes);
     uint32_t h_counters[2] = { 1u, 0u }, zero = 0;
-    BB_CHECK(hipMemcpy(counters, h_counters, sizeof(h_counters), hipMemcpyHostToDevice));
-    BB_CHECK(hipMemcpy(pending[0], &zero, sizeof(uint32_t), hipMemcpyHostToDevice));
-    BB_CHECK(hipMemset(flags + n, 0, sizeof(uint32_t)));
+    BB_CHECK0(hipMemcpy(counters, h_counters, sizeof(h_counters), hipMemcpyHostToDevice));
+    BB_CHECK0(hipMemcpy(pending[0], &zero, sizeof(uint32_t), hipMemcpyHostToDevice));
+    BB_CHECK0(hipMemset(flags + n, 0, sizeof(uint32_t)));
     uint32_t n_pending = n > 1 ? 1u : 0u;
     int cur = 0, pc = 0;
     for (uint32_t level = 0; n_pending > 0; level++) {
-        if (level > 4096) { err = "bvh_build: tree deeper than 4096 levels"; return false; }
+        if (level > 4096) { err = "bvh_build: tree deeper than 4096 levels"; return 0; }
         const unsigned gp = (n_pending + T - 1) / T;
-        BB_CHECK(hipcub::DeviceScan::InclusiveScan(tmp, tmp_bytes, start_mark, seg, hipcub::Max(), (int)n));
+        BB_CHECK0(hipcub::DeviceScan::InclusiveScan(tmp, tmp_bytes, start_mark, seg, hipcub::Max(), (int)n));
         hipLaunchKernelGGL(k_acc_reset, dim3((unsigned)(((size_t)n_pending * ACC_WORDS + T - 1) / T)), dim3(T), 0, 0, acc, n_pending);
         hipLaunchKernelGGL(k_bounds, dim3(gn), dim3(T), 0, 0, n, verts, idx[cur], seg, node_at_start, nodes, acc);
         hipLaunchKernelGGL(k_bin, dim3(gn), dim3(T), 0, 0, n, verts, idx[cur], seg, node_at_start, nodes, acc);
         hipLaunchKernelGGL(k_split, dim3(gp), dim3(T), 0, 0, n_pending, pending[pc], nodes, acc, splits);
         hipLaunchKernelGGL(k_flags, dim3(gn), dim3(T), 0, 0, n, verts, idx[cur], seg, node_at_start, nodes, splits, flags);
-        BB_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, flags, scan, (int)n + 1));
+        BB_CHECK0(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, flags, scan, (int)n + 1));
         hipLaunchKernelGGL(k_scatter, dim3(gn), dim3(T), 0, 0, n, idx[cur], idx[cur ^ 1], seg, node_at_start, nodes, splits, flags, scan);
-        BB_CHECK(hipMemset(counters + 1, 0, sizeof(uint32_t)));
+        BB_CHECK0(hipMemset(counters + 1, 0, sizeof(uint32_t)));
         hipLaunchKernelGGL(k_children, dim3(gp), dim3(T), 0, 0, n_pending, pending[pc], nodes, splits, scan, counters, pending[pc ^ 1], start_mark, node_at_start);
-        BB_CHECK(hipGetLastError());
-        BB_CHECK(hipMemcpy(h_counters, counters, sizeof(h_counters), hipMemcpyDeviceToHost));
-        if (h_counters[0] > max_nodes || h_counters[1] > max_pending) { err = "bvh_build: node bookkeeping overflow"; return false; }
+        BB_CHECK0(hipGetLastError());
+        BB_CHECK0(hipMemcpy(h_counters, counters, sizeof(h_counters), hipMemcpyDeviceToHost));
+        if (h_counters[0] > max_nodes || h_counters[1] > max_pending) { err = "bvh_build: node bookkeeping overflow"; return 0; }
         if (getenv("RT_BUILD_TIMING") && level < 12) fprintf(stderr, "  level %u (%u nodes) done at %.4f s\n", level, n_pending, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         n_pending = h_counters[1];
         cur ^= 1; pc ^= 1; levels = level + 1;
     }
-    if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "device bvh2: %u levels, levels done at %.3f s\n", levels, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-    std::vector<GNode> h_nodes(h_counters[0]);
-    BB_CHECK(hipMemcpy(h_nodes.data(), nodes, sizeof(GNode) * h_nodes.size(), hipMemcpyDeviceToHost));
-    out.order.resize(n);
-    BB_CHECK(hipMemcpy(out.order.data(), idx[cur], sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
-    out.nodes.resize(h_nodes.size());
-    for (size_t i = 0; i < h_nodes.size(); i++) {
-        const GNode& s = h_nodes[i]; Bvh2Node& o = out.nodes[i];
-        for (int k = 0; k < 3; k++) { o.lo[k] = s.lo[k]; o.hi[k] = s.hi[k]; }
-        o.left = s.left; o.right = s.right; o.begin = s.begin; o.count = s.count; o.depth = s.depth;
+    const uint32_t n_nodes = h_counters[0];
+    const uint32_t* order = idx[cur];
+    if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "device build: %u levels, binary tree done at %.3f s\n", levels, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+
+    // the host keeps the special case "the whole scene is one leaf slot" (root is a leaf, or two single-triangle children)
+    GNode h_root[3];
+    BB_CHECK0(hipMemcpy(&h_root[0], nodes, sizeof(GNode), hipMemcpyDeviceToHost));
+    if (h_root[0].left < 0) return 2;
+    BB_CHECK0(hipMemcpy(&h_root[1], nodes + h_root[0].left, sizeof(GNode), hipMemcpyDeviceToHost));
+    BB_CHECK0(hipMemcpy(&h_root[2], nodes + h_root[0].right, sizeof(GNode), hipMemcpyDeviceToHost));
+    if (h_root[1].left < 0 && h_root[1].count <= 1 && h_root[2].left < 0 && h_root[2].count <= 1) return 2;
+
+    // records + scene bounds, reference-topology nodes + statistics
+    struct Owned { void* p = nullptr; ~Owned() { if (p) (void)hipFree(p); } void* release() { void* q = p; p = nullptr; return q; } };
+    Owned o_tris, o_shade, o_nodes2, o_nodes4;
+    uint32_t *tri_mat, *keys;
+    BB_CHECK0(mem.alloc(&tri_mat, n)); BB_CHECK0(mem.alloc(&keys, 16));
+    BB_CHECK0(hipMalloc(&o_tris.p, sizeof(DTri) * (size_t)n)); BB_CHECK0(hipMalloc(&o_shade.p, sizeof(DTriShade) * (size_t)n));
+    BB_CHECK0(hipMalloc(&o_nodes2.p, sizeof(DNode2) * (size_t)n_nodes));
+    BB_CHECK0(hipMemcpy(tri_mat, d.tri_material, sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
+    const uint32_t h_keys[16] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, /* stats */ 0u, 0u, 0u };
+    BB_CHECK0(hipMemcpy(keys, h_keys, sizeof(h_keys), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_records, dim3(gn), dim3(T), 0, 0, n, verts, tri_mat, order, (DTri*)o_tris.p, (DTriShade*)o_shade.p, keys);
+    hipLaunchKernelGGL(k_nodes2, dim3((n_nodes + T - 1) / T), dim3(T), 0, 0, n_nodes, nodes, (DNode2*)o_nodes2.p, keys + 7);
+    BB_CHECK0(hipGetLastError());
+
+    // 4-wide collapse, level by level; the node array is sized by the tree (never more wide nodes than binary ones)
+    DNode4* wide; DWork* items[2]; uint32_t* need;
+    const size_t wide_cap = n;   // a wide node stands for an inner binary node, of which there are at most n - 1
+    BB_CHECK0(mem.alloc(&wide, wide_cap)); BB_CHECK0(mem.alloc(&items[0], wide_cap)); BB_CHECK0(mem.alloc(&items[1], wide_cap));
+    DWork root; memset(&root, 0, sizeof(root)); root.bnode = 0;
+    for (int k = 0; k < 3; k++) { root.lo[k] = h_root[0].lo[k]; root.hi[k] = h_root[0].hi[k]; }
+    BB_CHECK0(hipMemcpy(items[0], &root, sizeof(root), hipMemcpyHostToDevice));
+    std::vector<std::pair<uint32_t, uint32_t>> level_of;   // (first node, nodes) per level
+    uint32_t level_base = 0, n_items = 1;
+    int wc = 0;
+    while (n_items > 0) {
+        if ((size_t)level_base + n_items > wide_cap) { err = "bvh_build: wide tree larger than the binary tree"; return 0; }
+        const unsigned gi = (n_items + 1 + T - 1) / T;
+        hipLaunchKernelGGL(k_collapse_count, dim3(gi), dim3(T), 0, 0, n_items, nodes, items[wc], flags);
+        BB_CHECK0(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, flags, scan, (int)n_items + 1));
+        uint32_t n_next = 0;
+        BB_CHECK0(hipMemcpy(&n_next, scan + n_items, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const uint32_t next_base = level_base + n_items;
+        if ((size_t)next_base + n_next > wide_cap) { err = "bvh_build: wide tree larger than the binary tree"; return 0; }
+        hipLaunchKernelGGL(k_collapse_emit, dim3((n_items + T - 1) / T), dim3(T), 0, 0, n_items, level_base, next_base, nodes, items[wc], scan, wide, items[wc ^ 1]);
+        BB_CHECK0(hipGetLastError());
+        level_of.emplace_back(level_base, n_items);
+        level_base = next_base; n_items = n_next; wc ^= 1;
     }
-    if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "device bvh2: total %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-    return true;
+    const uint32_t n_wide = level_base;
+    if (n_wide > (1u << 25)) { err = "wide BVH exceeds 2^25 nodes (32-bit node offsets)"; return 0; }
+    BB_CHECK0(mem.alloc(&need, (size_t)n_wide));
+    for (size_t l = level_of.size(); l-- > 0;)
+        hipLaunchKernelGGL(k_stack_need, dim3((level_of[l].second + T - 1) / T), dim3(T), 0, 0, level_of[l].first, level_of[l].second, wide, need);
+    BB_CHECK0(hipGetLastError());
+    BB_CHECK0(hipMalloc(&o_nodes4.p, sizeof(DNode4) * (size_t)n_wide));
+    BB_CHECK0(hipMemcpy(o_nodes4.p, wide, sizeof(DNode4) * (size_t)n_wide, hipMemcpyDeviceToDevice));
+
+    // what the host needs to know
+    uint32_t r_keys[16], r_need = 0;
+    BB_CHECK0(hipMemcpy(r_keys, keys, sizeof(r_keys), hipMemcpyDeviceToHost));
+    BB_CHECK0(hipMemcpy(&r_need, need, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    hs.leaf_order.resize(n);
+    BB_CHECK0(hipMemcpy(hs.leaf_order.data(), order, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    auto unkey = [](uint32_t k) { uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k; float f; memcpy(&f, &b, 4); return f; };
+    for (int k = 0; k < 3; k++) { hs.bounds_lo[k] = unkey(r_keys[k]); hs.bounds_hi[k] = unkey(r_keys[3 + k]); }
+    memcpy(&hs.abs_max, &r_keys[6], 4);
+    hs.depth2 = r_keys[7]; hs.leaves2 = r_keys[8]; hs.max_leaf2 = r_keys[9];
+    hs.max_stack2 = hs.depth2 + 2;
+    hs.max_stack4 = r_need + 2;
+    hs.n_tris = n; hs.n_nodes2 = n_nodes; hs.n_nodes4 = n_wide;
+    out.tris = (DTri*)o_tris.release(); out.trishade = (DTriShade*)o_shade.release();
+    out.nodes2 = (DNode2*)o_nodes2.release(); out.nodes4 = (DNode4*)o_nodes4.release();
+    if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "device build: %u wide nodes in %zu levels, total %.3f s\n", n_wide, level_of.size(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    return 1;
+#undef BB_CHECK0
 }

@@ -159,7 +159,7 @@ static int upload(rt_scene* s, const std::vector<T>& v, const T** dst) {
 
 int rt_scene_persistent_blocks(const rt_scene* s) { return s->persistent_blocks; }
 
-bool device_bvh2_build(const float* h_verts, uint32_t n, Bvh2& out, std::string& err);   // bvh_build.hip
+int device_scene_build(const rt_scene_desc& d, HostScene& hs, DeviceGeometry& out, std::string& err);   // bvh_build.hip
 
 static int na_scratch_setup(int device);   // scratch of the no-allocation entry point (below)
 
@@ -176,23 +176,29 @@ extern "C" int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_
     }
     rt_scene* s = new rt_scene();
     std::string err;
-    if (!host_scene_build(*desc, s->host, err, flags == RT_SCENE_BUILD_HOST ? nullptr : device_bvh2_build)) {
-        rt_set_error("rt_scene_create: " + err); delete s; return RT_ERR_INVALID;
-    }
     int rc = RT_OK;
     auto fail = [&](int code) { rt_scene_destroy(s); return code; };
     if (hipGetDevice(&s->device) != hipSuccess) return fail(RT_ERR_DEVICE);
-    if ((rc = na_scratch_setup(s->device))) return fail(rc);
+    DeviceGeometry geom;
+    const bool built = host_scene_build(*desc, s->host, err, flags == RT_SCENE_BUILD_HOST ? nullptr : device_scene_build, &geom);
     HostScene& h = s->host;
     DScene& d = s->d;
-    if ((rc = upload(s, h.tris, &d.tris)) || (rc = upload(s, h.trishade, &d.trishade)) || (rc = upload(s, h.nodes4, &d.nodes4)) ||
-        (rc = upload(s, h.nodes2, &d.nodes2)) || (rc = upload(s, h.mats, &d.mats)) || (rc = upload(s, h.tex, &d.tex)) ||
-        (rc = upload(s, h.texels, &d.texels)) || (rc = upload(s, h.lights, &d.lights)))
+    if (geom.tris) {   // a device-side build leaves its arrays in device memory: they are the scene's from here on
+        for (void* p : { (void*)geom.tris, (void*)geom.trishade, (void*)geom.nodes4, (void*)geom.nodes2 }) s->allocs.push_back(p);
+        s->device_bytes += (uint64_t)h.n_tris * (sizeof(DTri) + sizeof(DTriShade)) + (uint64_t)h.n_nodes4 * sizeof(DNode4) + (uint64_t)h.n_nodes2 * sizeof(DNode2);
+        d.tris = geom.tris; d.trishade = geom.trishade; d.nodes4 = geom.nodes4; d.nodes2 = geom.nodes2;
+    }
+    if (!built) { rt_set_error("rt_scene_create: " + err); return fail(RT_ERR_INVALID); }
+    if ((rc = na_scratch_setup(s->device))) return fail(rc);
+    if (!geom.tris && ((rc = upload(s, h.tris, &d.tris)) || (rc = upload(s, h.trishade, &d.trishade)) || (rc = upload(s, h.nodes4, &d.nodes4)) ||
+                       (rc = upload(s, h.nodes2, &d.nodes2))))
+        return fail(rc);
+    if ((rc = upload(s, h.mats, &d.mats)) || (rc = upload(s, h.tex, &d.tex)) || (rc = upload(s, h.texels, &d.texels)) || (rc = upload(s, h.lights, &d.lights)))
         return fail(rc);
     d.env_cond = nullptr; d.env_marg = nullptr; d.env_func_int = h.env_func_int; d.env_nu = h.env_nu; d.env_nv = h.env_nv;
     if (!h.env_cond.empty() && ((rc = upload(s, h.env_cond, &d.env_cond)) || (rc = upload(s, h.env_marg, &d.env_marg)))) return fail(rc);
-    d.n_tris = (uint32_t)h.tris.size(); d.n_lights = (uint32_t)h.lights.size();
-    d.n_nodes4 = (uint32_t)h.nodes4.size(); d.n_nodes2 = (uint32_t)h.nodes2.size();
+    d.n_tris = h.n_tris; d.n_lights = (uint32_t)h.lights.size();
+    d.n_nodes4 = h.n_nodes4; d.n_nodes2 = h.n_nodes2;
     d.root_ref = d.n_tris ? 0u : RT_REF_EMPTY;
     d.max_stack4 = h.max_stack4; d.max_stack2 = h.max_stack2;
     d.abs_max = h.abs_max;
@@ -247,13 +253,21 @@ extern "C" int rt_scene_set_camera(rt_scene* s, const rt_camera* cam) {
 extern "C" int rt_scene_get_info(const rt_scene* s, rt_scene_info* o) {
     if (!s || !o) { rt_set_error("rt_scene_get_info: NULL argument"); return RT_ERR_INVALID; }
     const HostScene& h = s->host;
-    o->n_tris = (uint32_t)h.tris.size(); o->n_lights = (uint32_t)h.lights.size();
-    o->bvh2_nodes = (uint32_t)h.nodes2.size(); o->bvh2_depth = h.depth2; o->bvh2_leaves = h.leaves2; o->bvh2_max_leaf = h.max_leaf2;
-    o->wide_nodes = (uint32_t)h.nodes4.size(); o->wide_max_stack = h.max_stack4;
+    o->n_tris = h.n_tris; o->n_lights = (uint32_t)h.lights.size();
+    o->bvh2_nodes = h.n_nodes2; o->bvh2_depth = h.depth2; o->bvh2_leaves = h.leaves2; o->bvh2_max_leaf = h.max_leaf2;
+    o->wide_nodes = h.n_nodes4; o->wide_max_stack = h.max_stack4;
     o->device_bytes = s->device_bytes; o->build_seconds = (float)h.build_seconds;
     return RT_OK;
 }
 
+// The 4-wide tree as the kernels read it (128 B per node), copied back from device memory: lets a test compare the
+// device-side collapse with the host's, node for node.
+extern "C" int rt_scene_debug_wide_nodes(rt_scene* s, void* out, size_t max_nodes) {
+    if (!s || !out) { rt_set_error("rt_scene_debug_wide_nodes: NULL argument"); return RT_ERR_INVALID; }
+    if (max_nodes < s->host.n_nodes4) { rt_set_error("rt_scene_debug_wide_nodes: buffer too small"); return RT_ERR_INVALID; }
+    if (s->host.n_nodes4) RT_HIP(hipMemcpy(out, s->d.nodes4, (size_t)s->host.n_nodes4 * sizeof(DNode4), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
 extern "C" int rt_scene_leaf_order(const rt_scene* s, uint32_t* out) {
     if (!s || !out) { rt_set_error("rt_scene_leaf_order: NULL argument"); return RT_ERR_INVALID; }
     memcpy(out, s->host.leaf_order.data(), s->host.leaf_order.size() * sizeof(uint32_t));
@@ -268,9 +282,9 @@ extern "C" int rt_host_build_info(const rt_scene_desc* desc, uint32_t* leaf_orde
     if (leaf_order) memcpy(leaf_order, h.leaf_order.data(), h.leaf_order.size() * sizeof(uint32_t));
     if (info) {
         memset(info, 0, sizeof(*info));
-        info->n_tris = (uint32_t)h.tris.size(); info->n_lights = (uint32_t)h.lights.size();
-        info->bvh2_nodes = (uint32_t)h.nodes2.size(); info->bvh2_depth = h.depth2; info->bvh2_leaves = h.leaves2; info->bvh2_max_leaf = h.max_leaf2;
-        info->wide_nodes = (uint32_t)h.nodes4.size(); info->wide_max_stack = h.max_stack4; info->build_seconds = (float)h.build_seconds;
+        info->n_tris = h.n_tris; info->n_lights = (uint32_t)h.lights.size();
+        info->bvh2_nodes = h.n_nodes2; info->bvh2_depth = h.depth2; info->bvh2_leaves = h.leaves2; info->bvh2_max_leaf = h.max_leaf2;
+        info->wide_nodes = h.n_nodes4; info->wide_max_stack = h.max_stack4; info->build_seconds = (float)h.build_seconds;
     }
     return RT_OK;
 }

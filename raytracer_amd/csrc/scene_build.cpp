@@ -161,14 +161,15 @@ struct Builder {
 };
 
 // ---- 4-wide collapse -------------------------------------------------------------------------------------------
+// Numbered level by level: node 0 stands for the root; the inner children of a level's nodes, in (parent index, slot)
+// order, are the next level.  The numbering depends on the tree's shape alone, not on how a builder happened to number the
+// binary nodes, so the device-side collapse (bvh_build.hip), which works one level per launch, produces the same array.
 struct Slot { Aabb box; int bnode; /* >= 0: inner reference node to expand */ uint32_t first, count; /* leaf range */ };
+struct WorkItem { int bnode; /* >= 0: a reference node; -1: a leaf range longer than RT_LEAF_MAX, cut in up to four parts */ Aabb box; uint32_t first, count; };
 
-struct CollapseJob { int bnode; uint32_t parent; int slot; std::vector<DNode4> nodes; };
 struct Collapser {
     const std::vector<BNode>& bn;
     std::vector<DNode4>& out;
-    uint32_t cutoff = 0;                       // > 0: subtrees of at most this many triangles are left to `jobs`
-    std::vector<CollapseJob>* jobs = nullptr;
 
     bool single(int i) const { return bn[i].left < 0 && bn[i].count <= 1; }
     bool is_leaf(int i) const { return bn[i].left < 0; }
@@ -198,51 +199,54 @@ struct Collapser {
         }
         return n;
     }
-    // A leaf range longer than RT_LEAF_MAX becomes a small subtree of slots that all carry the leaf's box.
-    uint32_t emit_leaf(const Aabb& box, uint32_t first, uint32_t count, uint32_t& need) {
-        if (count <= RT_LEAF_MAX) { need = 0; return rt_make_leaf_ref(first, count); }
-        uint32_t ni = (uint32_t)out.size(); out.push_back(empty_node());
-        uint32_t parts = std::min<uint32_t>(4, (count + RT_LEAF_MAX - 1) / RT_LEAF_MAX);
-        uint32_t worst = 0;
-        for (uint32_t p = 0; p < parts; p++) {
-            uint32_t b = (uint32_t)((uint64_t)count * p / parts), e = (uint32_t)((uint64_t)count * (p + 1) / parts);
-            uint32_t nd = 0;
-            uint32_t ref = emit_leaf(box, first + b, e - b, nd);
-            set_child(out[ni], (int)p, box, ref);
-            worst = std::max(worst, nd);
+    // the up to four slots of the wide node that stands for `w`
+    int gather(const WorkItem& w, Slot* slots) const {
+        int ns = 0;
+        if (w.bnode < 0) {  // a long leaf range: parts that all carry the leaf's box
+            const uint32_t parts = std::min<uint32_t>(4, (w.count + RT_LEAF_MAX - 1) / RT_LEAF_MAX);
+            for (uint32_t p = 0; p < parts; p++) {
+                const uint32_t b = (uint32_t)((uint64_t)w.count * p / parts), e = (uint32_t)((uint64_t)w.count * (p + 1) / parts);
+                slots[ns].box = w.box; slots[ns].bnode = -1; slots[ns].first = w.first + b; slots[ns].count = e - b; ns++;
+            }
+            return ns;
         }
-        need = (parts - 1) + worst;
-        return ni;
-    }
-    // Emits the wide node that stands for reference node `b` (an inner node); returns its index.
-    uint32_t emit(int b, uint32_t& need) {
-        std::vector<Slot> slots;
-        slots.push_back(make_slot(bn[b].left, bn[b].box));
-        slots.push_back(make_slot(bn[b].right, bn[b].box));
-        while (slots.size() < 4) {
+        slots[ns++] = make_slot(bn[w.bnode].left, bn[w.bnode].box);
+        slots[ns++] = make_slot(bn[w.bnode].right, bn[w.bnode].box);
+        while (ns < 4) {  // open the inner slot with the largest box (the first of equals)
             int pick = -1; float best = -1.0f;
-            for (size_t i = 0; i < slots.size(); i++)
-                if (slots[i].bnode >= 0) { float a = slots[i].box.area(); if (a > best) { best = a; pick = (int)i; } }
+            for (int i = 0; i < ns; i++)
+                if (slots[i].bnode >= 0) { float a = slots[i].box.area(); if (a > best) { best = a; pick = i; } }
             if (pick < 0) break;
-            int e = slots[pick].bnode;
-            Slot l = make_slot(bn[e].left, bn[e].box), r = make_slot(bn[e].right, bn[e].box);
-            slots[pick] = l;
-            slots.insert(slots.begin() + pick + 1, r);
+            const int e = slots[pick].bnode;
+            const Slot l = make_slot(bn[e].left, bn[e].box), r = make_slot(bn[e].right, bn[e].box);
+            for (int i = ns; i > pick + 1; i--) slots[i] = slots[i - 1];
+            slots[pick] = l; slots[pick + 1] = r; ns++;
         }
-        uint32_t ni = (uint32_t)out.size(); out.push_back(empty_node());
-        uint32_t worst = 0;
-        for (size_t k = 0; k < slots.size(); k++) {
-            uint32_t nd = 0, ref;
-            if (slots[k].bnode >= 0 && cutoff && bn[slots[k].bnode].count <= cutoff) {
-                jobs->push_back(CollapseJob{ slots[k].bnode, ni, (int)k, {} });   // collapsed on another thread, spliced in later
-                ref = RT_REF_EMPTY;
-            } else if (slots[k].bnode >= 0) ref = emit(slots[k].bnode, nd);
-            else ref = emit_leaf(slots[k].box, slots[k].first, slots[k].count, nd);
-            set_child(out[ni], (int)k, slots[k].box, ref);
-            worst = std::max(worst, nd);
+        return ns;
+    }
+    void run(const WorkItem& root) {
+        std::vector<WorkItem> cur{ root }, next;
+        out.push_back(empty_node());
+        size_t level_base = 0;
+        while (!cur.empty()) {
+            const size_t next_base = level_base + cur.size();
+            next.clear();
+            for (size_t i = 0; i < cur.size(); i++) {
+                Slot slots[4];
+                const int ns = gather(cur[i], slots);
+                DNode4& n = out[level_base + i];
+                for (int k = 0; k < ns; k++) {
+                    uint32_t ref;
+                    if (slots[k].bnode >= 0) { ref = (uint32_t)(next_base + next.size()); next.push_back(WorkItem{ slots[k].bnode, slots[k].box, 0, 0 }); }
+                    else if (slots[k].count <= RT_LEAF_MAX) ref = rt_make_leaf_ref(slots[k].first, slots[k].count);
+                    else { ref = (uint32_t)(next_base + next.size()); next.push_back(WorkItem{ -1, slots[k].box, slots[k].first, slots[k].count }); }
+                    set_child(n, k, slots[k].box, ref);
+                }
+            }
+            out.resize(next_base + next.size(), empty_node());
+            level_base = next_base;
+            cur.swap(next);
         }
-        need = (uint32_t)(slots.size() - 1) + worst;
-        return ni;
     }
 };
 
@@ -263,7 +267,7 @@ inline float lum(const float* c) { return ((0.2126f * c[0]) + (0.7152f * c[1]) +
 
 }  // namespace
 
-bool host_scene_build(const rt_scene_desc& d, HostScene& hs, std::string& err, Bvh2Builder device_builder) {
+bool host_scene_build(const rt_scene_desc& d, HostScene& hs, std::string& err, DeviceSceneBuilder device_builder, DeviceGeometry* geom) {
     auto t0 = std::chrono::steady_clock::now();
     if (d.n_tris > RT_LEAF_FIRST_MASK) { err = "too many triangles (max 2^27-1)"; return false; }
     if (d.n_tris && (!d.verts || !d.tri_material)) { err = "verts/tri_material is NULL"; return false; }
@@ -340,22 +344,18 @@ bool host_scene_build(const rt_scene_desc& d, HostScene& hs, std::string& err, B
         hs.env_func_int = funcInt; hs.env_nu = nu; hs.env_nv = nv;
     }
 
+    std::vector<uint32_t> rank_of(d.n_tris);
+    int on_device = 2;
+    if (device_builder && geom) {
+        on_device = device_builder(d, hs, *geom, err);
+        if (on_device == 0) return false;
+    }
+    if (on_device == 1) {
+        for (uint32_t r = 0; r < d.n_tris; r++) rank_of[hs.leaf_order[r]] = r;
+    } else {
     // reference tree
     Builder b; b.verts = d.verts; b.n = d.n_tris;
-    if (device_builder && d.n_tris > 0) {
-        Bvh2 t;
-        if (!device_builder(d.verts, d.n_tris, t, err)) return false;
-        b.order.swap(t.order);
-        b.nodes.resize(t.nodes.size());
-        for (size_t i = 0; i < t.nodes.size(); i++) {
-            const Bvh2Node& s = t.nodes[i];
-            BNode& o = b.nodes[i];
-            o.box.lo = f3(s.lo[0], s.lo[1], s.lo[2]); o.box.hi = f3(s.hi[0], s.hi[1], s.hi[2]);
-            o.left = s.left; o.right = s.right; o.begin = s.begin; o.count = s.count; o.depth = s.depth;
-            b.max_depth = std::max(b.max_depth, s.depth);
-            if (s.left < 0) { o.first = s.begin; o.nleaf = s.count; b.leaves++; b.max_leaf = std::max(b.max_leaf, s.count); }
-        }
-    } else b.build();
+    b.build();
     if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "bvh2 build %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     hs.leaf_order = b.order;
     hs.depth2 = b.max_depth; hs.leaves2 = b.leaves; hs.max_leaf2 = b.max_leaf;
@@ -366,7 +366,6 @@ bool host_scene_build(const rt_scene_desc& d, HostScene& hs, std::string& err, B
     // bounds are folded in order below)
     Aabb bounds;
     hs.tris.resize(d.n_tris); hs.trishade.resize(d.n_tris);
-    std::vector<uint32_t> rank_of(d.n_tris);
     float amax = 0;
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const uint32_t nthr = (uint32_t)std::min<uint64_t>(std::min(16u, hw), std::max<uint64_t>(1, d.n_tris / 65536));
@@ -414,47 +413,16 @@ bool host_scene_build(const rt_scene_desc& d, HostScene& hs, std::string& err, B
         if (d.n_tris > 0) {
             Collapser col{ b.nodes, hs.nodes4 };
             const BNode& root = b.nodes[0];
-            uint32_t need = 0;
             if (root.left < 0 || (col.single(root.left) && col.single(root.right))) {
                 // the whole scene is one leaf slot; a single-triangle root has no real box anywhere above it
                 Aabb box = root.count >= 2 ? root.box : Aabb();
                 if (root.count < 2) { box.lo = f3(-Aabb::FLT_MAX_, -Aabb::FLT_MAX_, -Aabb::FLT_MAX_); box.hi = f3(Aabb::FLT_MAX_, Aabb::FLT_MAX_, Aabb::FLT_MAX_); }
-                hs.nodes4.push_back(Collapser::empty_node());
-                uint32_t nd = 0;
-                uint32_t ref = col.emit_leaf(box, 0, d.n_tris, nd);
-                Collapser::set_child(hs.nodes4[0], 0, box, ref);
-                need = nd;
-            } else {
-                // the top of the tree here, subtrees of <= n/64 triangles on worker threads into vectors of their own, then
-                // spliced behind it (inner references shifted by where each vector lands); same nodes, another numbering
-                std::vector<CollapseJob> jobs;
-                col.cutoff = d.n_tris >= (1u << 16) ? std::max<uint32_t>(1024u, d.n_tris / 64u) : 0u;
-                col.jobs = &jobs;
-                col.emit(0, need);
-                std::atomic<size_t> next{0};
-                auto work = [&]() {
-                    for (size_t j; (j = next.fetch_add(1)) < jobs.size();) {
-                        Collapser sub{ b.nodes, jobs[j].nodes };
-                        uint32_t nd = 0;
-                        sub.emit(jobs[j].bnode, nd);
-                    }
-                };
-                std::vector<std::thread> pool;
-                for (uint32_t ti = 1; ti < std::min<uint32_t>(nthr, (uint32_t)jobs.size()); ti++) pool.emplace_back(work);
-                work();
-                for (auto& t : pool) t.join();
-                for (CollapseJob& j : jobs) {
-                    const uint32_t base = (uint32_t)hs.nodes4.size();
-                    for (DNode4& n : j.nodes)
-                        for (int k = 0; k < 4; k++)
-                            if (n.child[k] != RT_REF_EMPTY && !(n.child[k] & RT_REF_LEAF)) n.child[k] += base;
-                    hs.nodes4.insert(hs.nodes4.end(), j.nodes.begin(), j.nodes.end());
-                    hs.nodes4[j.parent].child[j.slot] = base;
-                    std::vector<DNode4>().swap(j.nodes);
-                }
-                need = wide_stack_need(hs.nodes4, 0);
-            }
-            hs.max_stack4 = need + 2;
+                if (d.n_tris <= RT_LEAF_MAX) {
+                    hs.nodes4.push_back(Collapser::empty_node());
+                    Collapser::set_child(hs.nodes4[0], 0, box, rt_make_leaf_ref(0, d.n_tris));
+                } else col.run(WorkItem{ -1, box, 0, d.n_tris });
+            } else col.run(WorkItem{ 0, root.box, 0, 0 });
+            hs.max_stack4 = wide_stack_need(hs.nodes4, 0) + 2;
         }
         if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "  nodes2 + collapse thread done at %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     });
@@ -471,9 +439,14 @@ bool host_scene_build(const rt_scene_desc& d, HostScene& hs, std::string& err, B
     }
     hs.abs_max = amax;
     put3(hs.bounds_lo, bounds.lo); put3(hs.bounds_hi, bounds.hi);
-    F3 c = f3((bounds.hi.x + bounds.lo.x) * 0.5f, (bounds.hi.y + bounds.lo.y) * 0.5f, (bounds.hi.z + bounds.lo.z) * 0.5f);
-    put3(hs.centre, c);
-    hs.radius = length(sub(bounds.hi, c));
+    hs.n_tris = d.n_tris; hs.n_nodes4 = (uint32_t)hs.nodes4.size(); hs.n_nodes2 = (uint32_t)hs.nodes2.size();
+    }
+    {   // SceneBounds (SceneLoader.h:286-287)
+        F3 lo = f3(hs.bounds_lo[0], hs.bounds_lo[1], hs.bounds_lo[2]), hi = f3(hs.bounds_hi[0], hs.bounds_hi[1], hs.bounds_hi[2]);
+        F3 c = f3((hi.x + lo.x) * 0.5f, (hi.y + lo.y) * 0.5f, (hi.z + lo.z) * 0.5f);
+        put3(hs.centre, c);
+        hs.radius = length(sub(hi, c));
+    }
 
     if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "records + collapse done at %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     // light list: background first if it has power (Scene.h:164), then emissive triangles in caller order (Scene.h:107)

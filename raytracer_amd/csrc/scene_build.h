@@ -29,17 +29,22 @@ struct HostScene {
     std::vector<float> env_cond, env_marg;
     float env_func_int = 0; int32_t env_nu = 0, env_nv = 0;
     double build_seconds = 0;
+    // sizes of the geometry arrays (equal to the vectors' sizes after a host build; a device-side build leaves the vectors empty)
+    uint32_t n_tris = 0, n_nodes4 = 0, n_nodes2 = 0;
 };
 
-// The reference-topology binary tree as a builder hands it over: node 0 is the root, leaves have left == right == -1,
-// [begin, begin + count) is the node's range in `order` (= DFS leaf order: the partitions keep the left child first).
-// Nodes with count <= 1 keep the inverted default box (Geometry.h:401 returns before the bounds are grown).
-struct Bvh2Node { float lo[3], hi[3]; int32_t left, right; uint32_t begin, count, depth; };
-struct Bvh2 { std::vector<Bvh2Node> nodes; std::vector<uint32_t> order; };
-typedef bool (*Bvh2Builder)(const float* verts, uint32_t n_tris, Bvh2& out, std::string& err);
+// What a device-side build leaves in device memory (hipMalloc'ed; the caller owns the four arrays afterwards).
+struct DeviceGeometry { DTri* tris = nullptr; DTriShade* trishade = nullptr; DNode4* nodes4 = nullptr; DNode2* nodes2 = nullptr; };
+// Builds the binary tree, the triangle records, the reference-topology nodes and the 4-wide tree on the GPU and fills the
+// geometry fields of `hs` (leaf_order, statistics, stack bounds, scene bounds, sizes).  Returns 1 when it did, 2 when it
+// declines (scenes the host handles: an empty one, or a root that is a single leaf slot), 0 on error (`err`).
+typedef int (*DeviceSceneBuilder)(const rt_scene_desc& d, HostScene& hs, DeviceGeometry& out, std::string& err);
 
-// Returns false and fills `err` on invalid input.  `device_builder` (bvh_build.hip) replaces the host's own
-// binned-SAH build of the binary tree when given; everything downstream is the same code.
-bool host_scene_build(const rt_scene_desc& d, HostScene& out, std::string& err, Bvh2Builder device_builder = nullptr);
+// Returns false and fills `err` on invalid input.  With `device_builder` (bvh_build.hip) and `geom`, everything that is
+// per triangle or per node happens on the device and hs.tris / trishade / nodes4 / nodes2 stay empty (geom holds the device
+// arrays); without it the host builds them.  The 4-wide tree is numbered level by level either way: the two builds give
+// the same nodes4 array, byte for byte (tests/test_bvh_build_gpu.py).
+bool host_scene_build(const rt_scene_desc& d, HostScene& out, std::string& err, DeviceSceneBuilder device_builder = nullptr,
+                      DeviceGeometry* geom = nullptr);
 // Camera::init + Camera::updateView (Scene.h:26-45)
 void host_camera_build(const rt_camera& c, DCamera& out);

@@ -221,6 +221,52 @@ def test_converged_render_relmse():
     assert r < 1e-3, f"relMSE {r}"
 
 
+def test_converged_render_relmse_cornell_256():
+    """The same gate at BASELINE config 2's scale: Cornell box, 256 x 256, 4096 spp on both sides, independent seeds."""
+    ref = np.load(os.path.join(GOLDEN, "film_cornell256_4096.npy"))
+    got, _ = gpu_render(scenes.cornell(256, 256), api.PATH, 4096, seed=20240611)
+    assert np.isfinite(got).all()
+    r = rel_mse(got / 4096, ref)
+    assert r < 1e-3, f"relMSE {r}"
+
+
+@pytest.mark.parametrize("variant,fixture", [("bathroom", "film_bathroom240_32768.npy"), ("living-room", "film_livingroom240_32768.npy")])
+def test_converged_render_relmse_on_the_bench_workloads(variant, fixture):
+    """north_star image gate on the bench scenes themselves (configs 3-4: the default bathroom-class / living-room-class stand-ins,
+    1.1 M triangles, here at 240 x 135): relMSE < 1e-3 against the CPU render (oracle, 32768 spp, another seed;
+    tests/golden/make_film_golden_r2.py).  These interiors carry glass-to-light paths with a per-pixel relative variance
+    sigma^2 of about 10 (the test measures it from two GPU renders), so two independent 4096-spp films are ~5e-3 apart whoever
+    renders them: the bound is therefore checked where it is a statement about bias -- the GPU renders 65536 spp, which
+    leaves sigma^2 (1/65536 + 1/32768) ~ 5e-4 of noise -- and at 4096 spp the distance to the reference must be what the
+    measured variance predicts."""
+    path = os.path.join(GOLDEN, fixture)
+    if not os.path.exists(path):
+        pytest.skip(f"{fixture} has not been generated yet (tests/golden/make_film_golden_r2.py, about an hour of CPU)")
+    ref = np.load(path).astype(np.float64)
+    M, N = 32768, 65536
+    s = scenes.interior(variant, 1.0, 240, 135)
+    sc = api.Scene(s)
+    rt = api.RayTracer(sc)
+    g4a = g4b = None
+    for k in range(N // 4096):
+        rt.render(api.PATH, 4096, 424242, k * 4096)
+        if k == 0:
+            g4a = rt.film()[0].astype(np.float64) / 4096
+        if k == 1:
+            g4b = rt.film()[0].astype(np.float64) / 4096 * 2 - g4a      # the second 4096 samples alone
+    film, n = rt.film()
+    rt.close(); sc.close()
+    assert n == N and np.isfinite(film).all()
+    got = film.astype(np.float64) / N
+    r = rel_mse(got, ref)
+    assert r < 1e-3, f"relMSE {r}"
+    assert abs(got.mean() / ref.mean() - 1) < 5e-3
+    sigma2 = rel_mse(g4a, g4b) * 4096 / 2                                # relMSE of two independent n-spp films = 2 sigma^2 / n
+    predicted = sigma2 * (1 / 4096 + 1 / M)
+    r4 = rel_mse(g4a, ref)
+    assert 0.5 * predicted < r4 < 1.6 * predicted, (r4, predicted, sigma2)
+
+
 def test_specular_scene_matches_cpu_render_to_its_noise_floor():
     """Mirror + glass Cornell: specular-to-light paths (canHitLight after a specular bounce, Renderer.h:252) are
     fireflies, and neither renderer is converged at 4096 spp (two CPU-oracle seeds differ by relMSE ~1e-2 as well).
