@@ -44,7 +44,7 @@ struct RBuf {  // device buffers of one renderer
     float4* rad;
     uint32_t* q_active[2];
     uint32_t* q_class;   // RT_NCLASS * cap
-    uint32_t* cls;       // per path: BSDF class of the hit extend found, RT_CLS_NONE when the path ended
+    uint32_t* cls;       // per position of the active queue: BSDF class of the hit extend found, RT_CLS_NONE when the path ended
     float4* shadow;      // 3 * cap
     float4* gather;      // 4 * cap (radiosity requests)
     float4* vpl;         // 4 * vpl_cap
@@ -250,7 +250,7 @@ struct ExtendJob {
     __device__ __forceinline__ uint32_t path_of(uint32_t i) const { return first ? i : queue[i]; }
     __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d) {
         uint32_t path = path_of(i);
-        if (__float_as_uint(R.st[(size_t)path * 4 + 3].w) & RT_FLAG_DEAD) { R.cls[path] = RT_CLS_NONE; return false; }
+        if (__float_as_uint(R.st[(size_t)path * 4 + 3].w) & RT_FLAG_DEAD) { R.cls[i] = RT_CLS_NONE; return false; }
         float4 ro = R.st[(size_t)path * 4 + 0], rd = R.st[(size_t)path * 4 + 1];
         o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z);
         return true;
@@ -279,7 +279,7 @@ struct ExtendJob {
             col3 c = bg_evaluate(S, mk3(rd.x, rd.y, rd.z));
             R.rad[path] = make_float4(L.x + c.r, L.y + c.g, L.z + c.b, L.w);
         }
-        R.cls[path] = cls;
+        R.cls[i] = cls;   // by queue position, not by path: k_bin then streams through it
     }
 };
 // TAG only gives the launches of a one-stream renderer (rt_renderer_set_streams) a kernel name of their own, so that a
@@ -305,19 +305,47 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_extend(DScene S, RB
 // Material sorting: the hits extend left behind (R.cls per path) are binned into one queue per BSDF class, in
 // queue order, so a shade wave runs one material's code.  Block-lockstep: one atomic per class per 512 paths.
 #define RT_BIN_BLOCK 512
+#define RT_BIN_ITEMS 4   // paths per thread and block iteration: a block moves 2048 paths per atomic and class
+// One contended atomic on a counter costs ~11 ns whatever else the GPU does, so a launch over n paths cannot take less than
+// n / (paths per atomic) x 11 ns per class: with 512 paths per atomic that floor (0.25 ms at 12 M paths) was the kernel's
+// whole duration (PMC: VALU 0.04, TA 0.18 busy).  Slots keep queue order inside the block: (item, wave, lane).
 __global__ __launch_bounds__(RT_BIN_BLOCK) void k_bin(RBuf R, Ctl* ctl, int cur, int first) {
-    __shared__ uint32_t s_app[RT_NCLASS * (RT_BIN_BLOCK / 64 + 1)];
+    constexpr int NW = RT_BIN_BLOCK / 64, NV = NW * RT_BIN_ITEMS;   // waves, and (item, wave) pairs
+    __shared__ uint32_t s_app[RT_NCLASS * (NV + 1)];
     const uint32_t n = ctl->n_active[cur];
     const uint32_t* queue = R.q_active[cur];
-    for (uint32_t base = blockIdx.x * RT_BIN_BLOCK; base < n; base += gridDim.x * RT_BIN_BLOCK) {
-        uint32_t i = base + threadIdx.x, path = 0, c = RT_CLS_NONE;
-        if (i < n) { path = first ? i : queue[i]; c = R.cls[path]; }
-        uint32_t* const counters[RT_NCLASS] = { &ctl->n_class[0][0], &ctl->n_class[1][0], &ctl->n_class[2][0], &ctl->n_class[3][0], &ctl->n_class[4][0], &ctl->n_class[5][0] };
-        const bool pred[RT_NCLASS] = { c == 0, c == 1, c == 2, c == 3, c == 4, c == 5 };
-        uint32_t slot[RT_NCLASS];
-        block_append<RT_NCLASS, RT_BIN_BLOCK / 64>(counters, pred, slot, s_app);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ULL << lane) - 1ULL;
+    for (uint32_t base = blockIdx.x * (RT_BIN_BLOCK * RT_BIN_ITEMS); base < n; base += gridDim.x * (RT_BIN_BLOCK * RT_BIN_ITEMS)) {
+        uint32_t path[RT_BIN_ITEMS], c[RT_BIN_ITEMS], prefix[RT_BIN_ITEMS];
 #pragma unroll
-        for (int q = 0; q < RT_NCLASS; q++) if (pred[q]) R.q_class[(size_t)q * R.cap + slot[q]] = path;
+        for (int k = 0; k < RT_BIN_ITEMS; k++) {
+            const uint32_t i = base + (uint32_t)k * RT_BIN_BLOCK + threadIdx.x;
+            path[k] = 0; c[k] = RT_CLS_NONE; prefix[k] = 0;
+            if (i < n) { path[k] = first ? i : queue[i]; c[k] = R.cls[i]; }
+        }
+#pragma unroll
+        for (int k = 0; k < RT_BIN_ITEMS; k++)
+#pragma unroll
+            for (int q = 0; q < RT_NCLASS; q++) {
+                const unsigned long long m = __ballot(c[k] == (uint32_t)q);
+                if (c[k] == (uint32_t)q) prefix[k] = (uint32_t)__popcll(m & lt);
+                if (lane == 0) s_app[q * (NV + 1) + k * NW + (int)wave] = (uint32_t)__popcll(m);
+            }
+        __syncthreads();
+        if (threadIdx.x < RT_NCLASS) {
+            uint32_t* t = s_app + threadIdx.x * (NV + 1);
+            uint32_t sum = 0;
+            for (int v = 0; v < NV; v++) { const uint32_t cnt = t[v]; t[v] = sum; sum += cnt; }
+            t[NV] = sum ? atomicAdd(&ctl->n_class[threadIdx.x][0], sum) : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RT_BIN_ITEMS; k++)
+            if (c[k] < (uint32_t)RT_NCLASS) {
+                const uint32_t* t = s_app + c[k] * (NV + 1);
+                R.q_class[(size_t)c[k] * R.cap + t[NV] + t[k * NW + (int)wave] + prefix[k]] = path[k];
+            }
         __syncthreads();  // s_app is reused by the next iteration
     }
 }
@@ -326,7 +354,9 @@ __global__ __launch_bounds__(RT_BIN_BLOCK) void k_bin(RBuf R, Ctl* ctl, int cur,
 // Body of pathTrace after the hit (Renderer.h:232-252): NEE request (computeDirect, Renderer.h:155), depth
 // test, Russian roulette, BSDF sample, throughput update, next ray.  RADIOSITY adds the VPL gather request of
 // pathTraceRadiosity (Renderer.h:931).
+#ifndef RT_SHADE_BLOCK
 #define RT_SHADE_BLOCK 512
+#endif
 // ENV: the scene's light list holds an EnvironmentMap (its tabulated sampling costs 19 VGPRs; scenes without one run the lean instantiation)
 template <bool RADIOSITY, bool ENV>
 #ifndef RT_SHADE_OCC
@@ -1421,10 +1451,10 @@ static int render_path_like(rt_renderer* r, int mode, uint32_t batch, uint64_t s
         else if (r->lanes == 1) LAUNCHK(RT_KID_EXTEND, (k_extend<false, false, 1>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
         else LAUNCHK(RT_KID_EXTEND, (k_extend<false, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
         LAUNCH(k_bin, r->flat_blocks / 2, RT_BIN_BLOCK, R, r->ctl, cur, b == 0 ? 1 : 0);
-        if (radiosity && S.env_cond) LAUNCHK(RT_KID_SHADE, (k_shade<true, true>), r->flat_blocks / 2, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
-        else if (radiosity) LAUNCHK(RT_KID_SHADE, (k_shade<true, false>), r->flat_blocks / 2, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
-        else if (S.env_cond) LAUNCHK(RT_KID_SHADE, (k_shade<false, true>), r->flat_blocks / 2, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
-        else LAUNCHK(RT_KID_SHADE, (k_shade<false, false>), r->flat_blocks / 2, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
+        if (radiosity && S.env_cond) LAUNCHK(RT_KID_SHADE, (k_shade<true, true>), r->flat_blocks * 256 / RT_SHADE_BLOCK, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
+        else if (radiosity) LAUNCHK(RT_KID_SHADE, (k_shade<true, false>), r->flat_blocks * 256 / RT_SHADE_BLOCK, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
+        else if (S.env_cond) LAUNCHK(RT_KID_SHADE, (k_shade<false, true>), r->flat_blocks * 256 / RT_SHADE_BLOCK, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
+        else LAUNCHK(RT_KID_SHADE, (k_shade<false, false>), r->flat_blocks * 256 / RT_SHADE_BLOCK, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
         if (r->count_enabled) LAUNCHK(RT_KID_CONNECT, k_connect<true>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
         else LAUNCHK(RT_KID_CONNECT, k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
         if (radiosity) {
@@ -1491,8 +1521,8 @@ static int render_mlt(rt_renderer* r, uint32_t chains, uint64_t seed, uint64_t f
         LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n, n);
         LAUNCHK(RT_KID_EXTEND, (k_extend<false, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
         LAUNCH(k_bin, r->flat_blocks / 2, RT_BIN_BLOCK, R, r->ctl, cur, b == 0 ? 1 : 0);
-        if (S.env_cond) LAUNCHK(RT_KID_SHADE, (k_shade<false, true>), r->flat_blocks / 2, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
-        else LAUNCHK(RT_KID_SHADE, (k_shade<false, false>), r->flat_blocks / 2, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
+        if (S.env_cond) LAUNCHK(RT_KID_SHADE, (k_shade<false, true>), r->flat_blocks * 256 / RT_SHADE_BLOCK, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
+        else LAUNCHK(RT_KID_SHADE, (k_shade<false, false>), r->flat_blocks * 256 / RT_SHADE_BLOCK, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
         LAUNCHK(RT_KID_CONNECT, k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
     }
     LAUNCH(k_ctl_final, 1, 1, r->ctl);
