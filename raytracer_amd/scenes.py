@@ -304,15 +304,16 @@ def interior(variant="bathroom", detail=1.0, width=1920, height=1080, seed=1, co
     a mirror, a tiled floor with a bilinear checker texture, plastic/diffuse/glass/mirror materials and
     four ceiling panels.  Vertices carry a <=1e-3 seeded jitter so there are no exact coplanar duplicates.
 
-    The material mix of the default scene is SURVEY 8(d)'s (diffuse / glass / mirror / plastic), placed so that every
-    estimator in it stays finite and the converged-image gate can run on it.  Upstream's non-finite cases are opt-in variants
-    of the same geometry, reported separately: `conductor=True` makes the small sphere of the bathroom a rough conductor,
-    `dielectric=True` a rough ("frosted") dielectric, whose half-vector draw (Materials.h:571) yields inf / NaN
-    throughputs; `glazed=True` puts PlasticBSDF on the smooth-shaded curved fixtures as well.  On those, a camera ray
-    (whose direction upstream leaves un-normalised, |dir| ~ 1e-3, Scene.h:60) that meets the silhouette has wo.z < 3e-8 in
-    the shading frame, Fresnel rounds to exactly 1, kd = 0, the Phong term underflows and PlasticBSDF::sample returns
-    f = 0 with pdf = 0 (Materials.h:861-930): 0 / 0, about one NaN sample in 3 million at 1080p.  By default plastic
-    therefore sits on the flat-shaded parts (blinds, shelves), where that grazing angle has no measurable probability."""
+    The default scene holds only BSDFs whose upstream estimators stay finite (diffuse, Oren-Nayar, glass, mirror), so that
+    its film is finite and the converged-image gate can run on it.  Upstream's non-finite cases are opt-in variants of the
+    same geometry, reported separately: `conductor=True` makes the small sphere of the bathroom a rough conductor,
+    `dielectric=True` a rough ("frosted") dielectric, whose half-vector draw (Materials.h:571) yields inf / NaN throughputs;
+    `glazed=True` is SURVEY 8(d)'s full mix with PlasticBSDF on the fixtures, the blinds and the shelves.  A camera ray
+    (whose direction upstream leaves un-normalised, |dir| ~ 1e-3, Scene.h:60; a mirror passes that length on) that meets
+    plastic at grazing incidence has wo.z < 3e-8 in the shading frame, Fresnel rounds to exactly 1, kd = 0, the Phong term
+    underflows and PlasticBSDF::sample returns f = 0 with pdf = 0 (Materials.h:861-930): 0 / 0.  On the smooth-shaded
+    curved fixtures that is one NaN sample in 3 million at 1080p, on the flat slats one in 10^9 -- which of them depends
+    on the last bit of the Fresnel term, so GPU and CPU do not even meet it on the same samples."""
     rng = np.random.default_rng(seed + (0 if variant == "bathroom" else 1000))
     b = _Builder()
     tex = [solid((0.8, 0.8, 0.78)),                       # 0 wall paint
@@ -333,7 +334,7 @@ def interior(variant="bathroom", detail=1.0, width=1920, height=1080, seed=1, co
             Material(MIRROR, 3),                                        # 6 mirror
             Material(DIFFUSE, 4),                                       # 7
             Material(ORENNAYAR, 5, sigma=0.4),                          # 8
-            Material(PLASTIC, 7, int_ior=1.4, ext_ior=1.0, roughness=0.2),    # 9 slats
+            Material(PLASTIC, 7, int_ior=1.4, ext_ior=1.0, roughness=0.2) if glazed else Material(DIFFUSE, 7),   # 9 slats / shelves
             Material(DIELECTRIC, 3, int_ior=1.33, ext_ior=1.0, roughness=0.1) if dielectric  # 10 frosted (one-sided), opt-in
             else (Material(PLASTIC, 5, int_ior=1.33, ext_ior=1.0, roughness=0.1) if glazed else Material(DIFFUSE, 5))]   # 10 blue ball
     if conductor:
