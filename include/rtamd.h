@@ -99,6 +99,7 @@ typedef struct {
     uint64_t lane_slots, lane_busy;         /* closest-hit walks: 64 x wave traversal steps, and how many of those lanes held a ray */
     uint64_t any_lane_slots, any_lane_busy; /* the same for any-hit walks (SIMD lane occupancy = busy / slots) */
     uint64_t max_steps, any_max_steps;      /* most wave steps any single ray stayed in flight (its share of a launch's tail) */
+    uint64_t gate_refused, any_gate_refused; /* answers of the conservative wide walk that failed upstream's box test on the hit's gate box and were recomputed by the exact walk */
 } rt_counters;
 
 typedef struct rt_scene rt_scene;
@@ -128,6 +129,10 @@ int rt_scene_leaf_order(const rt_scene* scene, uint32_t* out_n_tris);
 /* The flattened 4-wide tree (wide_nodes x 128 B: lox[4] loy[4] loz[4] hix[4] hiy[4] hiz[4] child[4] pad[4]) as it sits in
  * device memory, for structural checks (device-side build == host build). */
 int rt_scene_debug_wide_nodes(rt_scene* scene, void* out, size_t max_nodes);
+/* The same tree as the traversal kernels read it (wide_nodes x 64 B: org[3] scale[3] lox loy loz hix hiy hiz child[4]; child k's box
+ * is org + byte k of the plane word x scale, lo rounded down, hi up) and the per-triangle gate boxes (n_tris x 32 B: lo[3] pad hi[3] pad,
+ * in DFS leaf order: the reference box whose rayAABB (Geometry.h:207) decides whether upstream tests that triangle).  Either may be NULL. */
+int rt_scene_debug_walk_nodes(rt_scene* scene, void* nodes_out, size_t max_nodes, void* gate_out, size_t max_tris);
 /* Host-only structure query: runs the same builder without touching a device (leaf_order/info may be NULL).
  * Not a compute path: nothing can be traversed or rendered without a GPU. */
 int rt_host_build_info(const rt_scene_desc* desc, uint32_t* leaf_order, rt_scene_info* info);

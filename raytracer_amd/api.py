@@ -40,7 +40,7 @@ class Counters(C.Structure):
     _fields_ = [("closest_rays", C.c_uint64), ("any_rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
                 ("exact_path_rays", C.c_uint64), ("any_nodes_visited", C.c_uint64), ("any_tris_tested", C.c_uint64),
                 ("lane_slots", C.c_uint64), ("lane_busy", C.c_uint64), ("any_lane_slots", C.c_uint64), ("any_lane_busy", C.c_uint64),
-                ("max_steps", C.c_uint64), ("any_max_steps", C.c_uint64)]
+                ("max_steps", C.c_uint64), ("any_max_steps", C.c_uint64), ("gate_refused", C.c_uint64), ("any_gate_refused", C.c_uint64)]
 
     def asdict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -57,6 +57,7 @@ SYMBOLS = [
     "rt_film_set_spp", "rt_vpl_trace", "rt_vpl_count", "rt_render_counters", "rt_renderer_sync", "rt_film_save_hdr",
     "rt_film_tonemap", "rt_profile_enable", "rt_profile_read", "rt_debug_bsdf_sample", "rt_debug_bsdf_eval", "rt_debug_rng", "rt_matrix_invert", "rt_scene_create_ex",
     "rt_renderer_set_filter", "rt_render_aov", "rt_intersect_closest_noalloc", "rt_renderer_set_streams", "rt_debug_env", "rt_scene_debug_wide_nodes",
+    "rt_scene_debug_walk_nodes",
 ]
 
 
@@ -90,6 +91,7 @@ def lib():
         _sig(L, "rt_scene_get_info", [vp, C.POINTER(SceneInfo)])
         _sig(L, "rt_scene_leaf_order", [vp, vp])
         _sig(L, "rt_scene_debug_wide_nodes", [vp, vp, sz])
+        _sig(L, "rt_scene_debug_walk_nodes", [vp, vp, sz, vp, sz])
         _sig(L, "rt_host_build_info", [C.POINTER(SceneDesc), vp, C.POINTER(SceneInfo)])
         _sig(L, "rt_intersect_closest", [vp, vp, sz, vp, i32])
         _sig(L, "rt_intersect_closest_dev", [vp, vp, sz, vp, i32, vp])
@@ -198,6 +200,14 @@ class Scene:
         out = np.zeros(n, np.dtype([("box", np.float32, (6, 4)), ("child", np.uint32, 4), ("pad", np.uint32, 4)]))
         _check(self.L.rt_scene_debug_wide_nodes(self.h, out.ctypes.data, n), "rt_scene_debug_wide_nodes")
         return out
+
+    def walk_nodes(self):
+        """(nodes, gate): the 64-B nodes the traversal kernels read and the per-triangle gate boxes (DFS leaf order)."""
+        n = self.info()["wide_nodes"]
+        nodes = np.zeros(n, np.dtype([("org", np.float32, 3), ("scale", np.float32, 3), ("lo", np.uint8, (3, 4)), ("hi", np.uint8, (3, 4)), ("child", np.uint32, 4)]))
+        gate = np.zeros(self.ntris, np.dtype([("lo", np.float32, 3), ("pad0", np.float32), ("hi", np.float32, 3), ("pad1", np.float32)]))
+        _check(self.L.rt_scene_debug_walk_nodes(self.h, nodes.ctypes.data, n, gate.ctypes.data, self.ntris), "rt_scene_debug_walk_nodes")
+        return nodes, gate
 
     # Scene::traverse (Scene.h:118)
     def traverse(self, rays, mode=0):

@@ -396,8 +396,8 @@ __global__ void k_collapse_emit(uint32_t n_items, uint32_t level_base, uint32_t 
     DSlot slots[4];
     const int ns = d_gather(nodes, items[i], slots);
     DNode4 n;
-    const float qnan = __uint_as_float(0x7FC00000u);
-    for (int k = 0; k < 4; k++) { n.child[k] = RT_REF_EMPTY; n.pad[k] = 0u; n.lox[k] = n.loy[k] = n.loz[k] = n.hix[k] = n.hiy[k] = n.hiz[k] = qnan; }
+    const float inf = __uint_as_float(0x7F800000u);   // the empty box, as scene_build.cpp's empty_node()
+    for (int k = 0; k < 4; k++) { n.child[k] = RT_REF_EMPTY; n.pad[k] = 0u; n.lox[k] = n.loy[k] = n.loz[k] = inf; n.hix[k] = n.hiy[k] = n.hiz[k] = -inf; }
     uint32_t slot_of_next = scan[i];
     for (int k = 0; k < ns; k++) {
         const DSlot& s = slots[k];

@@ -144,6 +144,82 @@ __global__ void k_generate_rays(DScene S, const float* __restrict__ xy, size_t n
     r[0] = org.x; r[1] = org.y; r[2] = org.z; r[3] = dir.x; r[4] = dir.y; r[5] = dir.z;
 }
 
+// ------------------------------------------------------------------------------------------------ the walk's view of the tree
+// nodes4 (the builders' output, float boxes) -> nodesq (64 B per node, child boxes on a 256-step grid of the node's own box,
+// rounded outwards) + gate (per triangle, the float box of its leaf slot: what rt_settle tests with upstream's expression).
+// One thread per node.  The grid arithmetic is done in double: a plane that lands a rounding error (2^-52 of the node's
+// extent) inside the box it should contain is covered many times over by the walk's slack (2^-17 of the scene's extent).
+__global__ void k_quantise(const DNode4* __restrict__ in, uint32_t n, const DTri* __restrict__ tris, DNodeQ* __restrict__ out, DGate* __restrict__ gate) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DNode4 nd = in[i];
+    // What the walk culls with.  Inner child: the reference node's box.  Leaf slot: the bounds of its triangles' vertices --
+    // what a hit needs is that the slot's box holds the triangle; the slot's reference box (the gate, below) can be far
+    // larger: a single-triangle leaf carries its parent's box, a one-triangle scene a box of +-FLT_MAX.
+    float lo[3][4], hi[3][4];
+    for (int k = 0; k < 4; k++) {
+        const uint32_t ref = nd.child[k];
+        lo[0][k] = nd.lox[k]; lo[1][k] = nd.loy[k]; lo[2][k] = nd.loz[k]; hi[0][k] = nd.hix[k]; hi[1][k] = nd.hiy[k]; hi[2][k] = nd.hiz[k];
+        if (ref != RT_REF_EMPTY && (ref & RT_REF_LEAF)) {
+            const uint32_t first = ref & RT_LEAF_FIRST_MASK, cnt = ((ref >> 27) & 15u) + 1u;
+            for (int a = 0; a < 3; a++) { lo[a][k] = RT_INF; hi[a][k] = -RT_INF; }
+            for (uint32_t t = 0; t < cnt; t++) {
+                const DTri& tr = tris[first + t];
+                for (int a = 0; a < 3; a++) {
+                    lo[a][k] = fminf(lo[a][k], fminf(tr.v0[a], fminf(tr.v1[a], tr.v2[a])));
+                    hi[a][k] = fmaxf(hi[a][k], fmaxf(tr.v0[a], fmaxf(tr.v1[a], tr.v2[a])));
+                }
+            }
+        }
+    }
+    DNodeQ q;
+    float scale[3];
+    uint32_t wlo[3], whi[3];
+    for (int a = 0; a < 3; a++) {
+        float org = RT_INF, top = -RT_INF;
+        for (int k = 0; k < 4; k++)
+            if (nd.child[k] != RT_REF_EMPTY) { org = fminf(org, lo[a][k]); top = fmaxf(top, hi[a][k]); }
+        if (!(org <= top)) { org = 0.0f; top = 0.0f; }   // a node without children (the root of an empty scene is never read)
+        const double ext = (double)top - (double)org;
+        double s = 0.0;
+        if (ext > 0.0) {
+            int e; (void)frexp(ext / 255.0, &e);          // ext / 255 = m * 2^e, m in [0.5, 1)
+            if (e < -126) e = -126;                         // keep the step a normal float
+            s = ldexp(1.0, e);
+        }
+        for (;;) {
+            bool fits = true;
+            uint32_t l = 0, h = 0;
+            for (int k = 0; k < 4; k++) {
+                uint32_t ql = 255u, qh = 0u;                // unused slot: an inverted box (the walk also tests the child word)
+                if (nd.child[k] != RT_REF_EMPTY && s > 0.0) {
+                    const double fl = floor(((double)lo[a][k] - (double)org) / s), ce = ceil(((double)hi[a][k] - (double)org) / s);
+                    if (ce > 255.0) { fits = false; break; }
+                    ql = fl < 0.0 ? 0u : (uint32_t)fl; qh = (uint32_t)ce;
+                } else if (nd.child[k] != RT_REF_EMPTY) { ql = 0u; qh = 0u; }
+                l |= ql << (8 * k); h |= qh << (8 * k);
+            }
+            if (fits) { wlo[a] = l; whi[a] = h; break; }
+            s *= 2.0;
+        }
+        q.org[a] = org; scale[a] = (float)s;
+    }
+    q.scale_x = scale[0]; q.scale_y = scale[1]; q.scale_z = scale[2];
+    q.lox = wlo[0]; q.loy = wlo[1]; q.loz = wlo[2]; q.hix = whi[0]; q.hiy = whi[1]; q.hiz = whi[2];
+    for (int k = 0; k < 4; k++) {
+        const uint32_t ref = nd.child[k];
+        q.child[k] = ref;
+        if (ref != RT_REF_EMPTY && (ref & RT_REF_LEAF)) {
+            const uint32_t first = ref & RT_LEAF_FIRST_MASK, cnt = ((ref >> 27) & 15u) + 1u;
+            DGate g;
+            g.lo[0] = nd.lox[k]; g.lo[1] = nd.loy[k]; g.lo[2] = nd.loz[k]; g.pad0 = 0.0f;
+            g.hi[0] = nd.hix[k]; g.hi[1] = nd.hiy[k]; g.hi[2] = nd.hiz[k]; g.pad1 = 0.0f;
+            for (uint32_t t = 0; t < cnt; t++) gate[first + t] = g;
+        }
+    }
+    out[i] = q;
+}
+
 // ------------------------------------------------------------------------------------------------ scene
 template <class T>
 static int upload(rt_scene* s, const std::vector<T>& v, const T** dst) {
@@ -199,6 +275,20 @@ extern "C" int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_
     if (!h.env_cond.empty() && ((rc = upload(s, h.env_cond, &d.env_cond)) || (rc = upload(s, h.env_marg, &d.env_marg)))) return fail(rc);
     d.n_tris = h.n_tris; d.n_lights = (uint32_t)h.lights.size();
     d.n_nodes4 = h.n_nodes4; d.n_nodes2 = h.n_nodes2;
+    {   // the walk's own arrays, derived on the device from whichever builder made nodes4
+        void* pq = nullptr; void* pg = nullptr;
+        const size_t bq = sizeof(DNodeQ) * std::max<size_t>(h.n_nodes4, 1), bg = sizeof(DGate) * std::max<size_t>(h.n_tris, 1);
+        if (hipMalloc(&pq, bq) != hipSuccess) { rt_set_error("rt_scene_create: out of device memory (walk nodes)"); return fail(RT_ERR_NOMEM); }
+        s->allocs.push_back(pq);
+        if (hipMalloc(&pg, bg) != hipSuccess) { rt_set_error("rt_scene_create: out of device memory (gate boxes)"); return fail(RT_ERR_NOMEM); }
+        s->allocs.push_back(pg);
+        s->device_bytes += bq + bg;
+        d.nodesq = (const DNodeQ*)pq; d.gate = (const DGate*)pg;
+        if (h.n_nodes4) {
+            hipLaunchKernelGGL(k_quantise, dim3((h.n_nodes4 + 255u) / 256u), dim3(256), 0, 0, d.nodes4, h.n_nodes4, d.tris, (DNodeQ*)pq, (DGate*)pg);
+            if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { rt_set_error("rt_scene_create: k_quantise failed"); return fail(RT_ERR_DEVICE); }
+        }
+    }
     d.root_ref = d.n_tris ? 0u : RT_REF_EMPTY;
     d.max_stack4 = h.max_stack4; d.max_stack2 = h.max_stack2;
     d.abs_max = h.abs_max;
@@ -268,6 +358,14 @@ extern "C" int rt_scene_debug_wide_nodes(rt_scene* s, void* out, size_t max_node
     if (s->host.n_nodes4) RT_HIP(hipMemcpy(out, s->d.nodes4, (size_t)s->host.n_nodes4 * sizeof(DNode4), hipMemcpyDeviceToHost));
     return RT_OK;
 }
+// The same tree as the walk reads it (64 B per node) and the per-triangle gate boxes (32 B each); either pointer may be NULL.
+extern "C" int rt_scene_debug_walk_nodes(rt_scene* s, void* nodes_out, size_t max_nodes, void* gate_out, size_t max_tris) {
+    if (!s) { rt_set_error("rt_scene_debug_walk_nodes: NULL scene"); return RT_ERR_INVALID; }
+    if ((nodes_out && max_nodes < s->host.n_nodes4) || (gate_out && max_tris < s->host.n_tris)) { rt_set_error("rt_scene_debug_walk_nodes: buffer too small"); return RT_ERR_INVALID; }
+    if (nodes_out && s->host.n_nodes4) RT_HIP(hipMemcpy(nodes_out, s->d.nodesq, (size_t)s->host.n_nodes4 * sizeof(DNodeQ), hipMemcpyDeviceToHost));
+    if (gate_out && s->host.n_tris) RT_HIP(hipMemcpy(gate_out, s->d.gate, (size_t)s->host.n_tris * sizeof(DGate), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
 extern "C" int rt_scene_leaf_order(const rt_scene* s, uint32_t* out) {
     if (!s || !out) { rt_set_error("rt_scene_leaf_order: NULL argument"); return RT_ERR_INVALID; }
     memcpy(out, s->host.leaf_order.data(), s->host.leaf_order.size() * sizeof(uint32_t));
@@ -303,6 +401,7 @@ extern "C" int rt_counters_read(rt_scene* s, rt_counters* o, int reset) {
     o->closest_rays = c.closest; o->any_rays = c.any; o->nodes_visited = c.nodes; o->tris_tested = c.tris; o->exact_path_rays = c.exact;
     o->any_nodes_visited = c.any_nodes; o->any_tris_tested = c.any_tris;
     o->lane_slots = c.slots; o->lane_busy = c.busy; o->any_lane_slots = c.any_slots; o->any_lane_busy = c.any_busy; o->max_steps = c.max_steps; o->any_max_steps = c.any_max_steps;
+    o->gate_refused = c.refused; o->any_gate_refused = c.any_refused;
     if (reset) RT_HIP(hipMemset(s->d_counters, 0, sizeof(DCounters)));
     return RT_OK;
 }

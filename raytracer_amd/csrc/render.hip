@@ -1743,6 +1743,7 @@ extern "C" int rt_render_counters(rt_renderer* r, rt_counters* o, int reset) {
     o->closest_rays = c.tot_closest; o->any_rays = c.tot_any; o->nodes_visited = d.nodes; o->tris_tested = d.tris; o->exact_path_rays = d.exact;
     o->any_nodes_visited = d.any_nodes; o->any_tris_tested = d.any_tris;
     o->lane_slots = d.slots; o->lane_busy = d.busy; o->any_lane_slots = d.any_slots; o->any_lane_busy = d.any_busy; o->max_steps = d.max_steps; o->any_max_steps = d.any_max_steps;
+    o->gate_refused = d.refused; o->any_gate_refused = d.any_refused;
     if (reset) {
         RT_HIP(hipMemset(r->ctl, 0, sizeof(Ctl)));
         if (r->other_ready) RT_HIP(hipMemset(r->other.ctl, 0, sizeof(Ctl)));

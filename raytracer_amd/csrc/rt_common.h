@@ -5,7 +5,12 @@
 //              reference tree, so "first visited wins ties" (Geometry.h:449) becomes
 //              "lowest index wins".  One lane fetches one record as 4 x dwordx4.
 //   trishade : 64 B / triangle (vertex normals, uvs, area), same order; only read at a hit.
-//   nodes4   : 128 B (one L2 line) per 4-wide node: SoA child boxes + child refs.
+//   nodes4   : 128 B (one L2 line) per 4-wide node: SoA child boxes + child refs.  What the builders produce; the walk reads
+//   nodesq   : 64 B per 4-wide node, the same tree with the child boxes on a 256-step grid of the node's own box, rounded
+//              outwards.  A lane fetches a node as 4 x dwordx4 instead of 7: the traversal kernels are bound by the number of
+//              divergent load instructions per step, not by arithmetic.
+//   gate     : 32 B per triangle: the reference box whose rayAABB decides whether upstream tests that triangle at all
+//              (its leaf's box, or the parent's for a single-triangle leaf); read once per ray, for the hit it reports.
 //   nodes2   : 48 B per node of the reference-topology binary tree (validation / fallback walk).
 #pragma once
 #include <stdint.h>
@@ -38,12 +43,19 @@ struct DNode4 {      // 128 B
     uint32_t child[4];
     uint32_t pad[4];
 };
+struct DNodeQ {      // 64 B: child k's box is org + q * scale per axis, q = byte k of the plane words (lo rounded down, hi up)
+    float org[3]; float scale_x;
+    float scale_y, scale_z; uint32_t lox, loy;
+    uint32_t loz, hix, hiy, hiz;
+    uint32_t child[4];   // as DNode4::child; the walk tells unused slots by RT_REF_EMPTY here
+};
+struct DGate { float lo[3], pad0, hi[3], pad1; };   // 32 B
 struct DNode2 {      // 48 B, reference-topology node (BVHNode, Geometry.h:290): leaf <=> left < 0 && right < 0
     float lo[3]; int32_t left;
     float hi[3]; int32_t right;
     int32_t first, count, pad0, pad1;
 };
-static_assert(sizeof(DTri) == 64 && sizeof(DTriShade) == 64 && sizeof(DNode4) == 128 && sizeof(DNode2) == 48, "layout");
+static_assert(sizeof(DTri) == 64 && sizeof(DTriShade) == 64 && sizeof(DNode4) == 128 && sizeof(DNode2) == 48 && sizeof(DNodeQ) == 64 && sizeof(DGate) == 32, "layout");
 
 struct DMaterial {   // 80 B
     uint32_t type;       // RT_MAT_*
@@ -78,6 +90,8 @@ struct DScene {
     const DTri* tris;
     const DTriShade* trishade;
     const DNode4* nodes4;
+    const DNodeQ* nodesq;
+    const DGate* gate;
     const DNode2* nodes2;
     const DMaterial* mats;
     const DTexture* tex;
@@ -96,4 +110,4 @@ struct DScene {
     DCamera cam;
 };
 
-struct DCounters { unsigned long long closest, any, nodes, tris, exact, any_nodes, any_tris, slots, busy, any_slots, any_busy, max_steps, any_max_steps; };
+struct DCounters { unsigned long long closest, any, nodes, tris, exact, any_nodes, any_tris, slots, busy, any_slots, any_busy, max_steps, any_max_steps, refused, any_refused; };

@@ -312,12 +312,13 @@ __device__ bool rt_walk_exact(const DScene& S, f3 o, f3 dir, float maxT, HitRec&
 // scalar delta * max |1/dir|, which let axis-parallel shadow rays walk everything behind them: k_connect -6 %).
 struct Walk {
     f3 o, dir, inv;
-    f3 pad;        // closest hit
+    f3 pad;        // the slack in t per axis: delta * |1/dir|
     float maxT;        // any hit
-    HitRec best;
+    HitRec best;       // closest hit so far; any hit: best.rank = the blocker that was found
     uint32_t cur, sp;
-    uint32_t sx, sy, sz;   // 48 where 1/dir is negative on that axis, else 0: byte distance from a node's lo plane row to its hi row
+    uint32_t mx, my, mz;   // all ones where 1/dir is negative on that axis, else 0: picks a node's hi planes as the near planes
     bool occluded;
+    bool wide;         // this item went through the 4-wide walk: its answer still has to pass rt_settle
 };
 __device__ __forceinline__ void rt_walk_init(const DScene& S, Walk& w, f3 o, f3 dir, f3 inv, float maxT) {
     float scale = fmaxf(S.abs_max, fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))));
@@ -325,55 +326,58 @@ __device__ __forceinline__ void rt_walk_init(const DScene& S, Walk& w, f3 o, f3 
     w.o = o; w.dir = dir; w.inv = inv;
     w.pad = mk3(delta * fabsf(inv.x), delta * fabsf(inv.y), delta * fabsf(inv.z));
     w.maxT = maxT;
-    w.sx = inv.x < 0.0f ? 48u : 0u; w.sy = inv.y < 0.0f ? 48u : 0u; w.sz = inv.z < 0.0f ? 48u : 0u;
-    w.cur = S.root_ref; w.sp = 0; w.occluded = false;
+    w.mx = inv.x < 0.0f ? 0xFFFFFFFFu : 0u; w.my = inv.y < 0.0f ? 0xFFFFFFFFu : 0u; w.mz = inv.z < 0.0f ? 0xFFFFFFFFu : 0u;
+    w.cur = S.root_ref; w.sp = 0; w.occluded = false; w.wide = true;
 }
 // Box tests of one 4-wide node: pushes the passing children but the nearest, which becomes w.cur (returns true).
-// (Writing the slab arithmetic on child pairs so that it compiles to v_pk_add_f32 / v_pk_mul_f32 measured 20 % slower
-// in k_extend: the register shuffling costs more than the packed ops save; the build also passes -fno-slp-vectorize.)
+//
+// The tests are CONSERVATIVE ONLY.  Upstream's answer is min (t, DFS rank) over the triangles that pass rayIntersect AND whose
+// ancestor boxes all pass rayAABB; for a tame ray the box test is monotone under containment (section 3 of DESIGN.md), so the
+// second condition is "the triangle's gate box passes" (DScene::gate).  The walk may therefore use any boxes and any
+// arithmetic that never skip a true hit nearer than the best so far -- here the child boxes on a 256-step grid of the node's
+// box, rounded outwards, grown by the slack `pad`, evaluated with one fma per plane -- as long as the hit it ends with is then
+// checked against its gate box with upstream's own expression (rt_settle): if that check fails, which takes a hit within
+// rounding of its gate box's surface, the ray is walked again by rt_walk_exact.
+//   plane in t:  (org + q * s - o) * inv -+ pad  =  q * (s * inv) + ((org - o) * inv -+ pad)  =  fma(q, A, B)
+// Rounding: org - o, B and the final fma round once each, <= 3 * 2^-24 * 3 M |1/dir|, inside the slack's budget (rt_walk_init).
+// (Writing the slab arithmetic on child pairs as v_pk_* measured slower in round 1; the build passes -fno-slp-vectorize.)
 #ifndef RT_POP_FAST
 #define RT_POP_FAST 1
 #endif
-// The node's plane rows are fetched near-plane first: on an axis where 1/dir is negative the entry plane is hi, so
-// the lane reads the hi row where the others read lo (an address choice, not a select).  For lo <= hi and a finite
-// non-NaN 1/dir, (near - o) * inv == Min((lo - o) * inv, (hi - o) * inv) bit for bit (rounding is monotonic), which is
-// AABB::rayAABB's tmin/tmax ordering (Geometry.h:213-221) without the six min/max per child.  Unused child slots
-// hold NaN boxes and fail `tentry <= texit` by themselves.
+__device__ __forceinline__ uint32_t rt_bfi(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); }   // v_bfi_b32
+__device__ __forceinline__ float rt_ub0(uint32_t v) { return (float)(v & 255u); }            // v_cvt_f32_ubyte0..3
+__device__ __forceinline__ float rt_ub1(uint32_t v) { return (float)((v >> 8) & 255u); }
+__device__ __forceinline__ float rt_ub2(uint32_t v) { return (float)((v >> 16) & 255u); }
+__device__ __forceinline__ float rt_ub3(uint32_t v) { return (float)(v >> 24); }
 template <bool ANY>
 __device__ __forceinline__ bool rt_node_eval(const DScene& S, Walk& w, TravStack& st) {
-    const char* nb = reinterpret_cast<const char*>(S.nodes4);
-    const uint32_t base = w.cur << 7;   // < 2^32: the host caps the wide tree at 2^25 nodes
-    const float4 nx = *reinterpret_cast<const float4*>(nb + (base + w.sx));
-    const float4 ny = *reinterpret_cast<const float4*>(nb + ((base + 16u) + w.sy));
-    const float4 nz = *reinterpret_cast<const float4*>(nb + ((base + 32u) + w.sz));
-    const float4 fx = *reinterpret_cast<const float4*>(nb + ((base + 48u) - w.sx));
-    const float4 fy = *reinterpret_cast<const float4*>(nb + ((base + 64u) - w.sy));
-    const float4 fz = *reinterpret_cast<const float4*>(nb + ((base + 80u) - w.sz));
-    const uint4 ch = *reinterpret_cast<const uint4*>(nb + (base + 96u));
+    const char* nb = reinterpret_cast<const char*>(S.nodesq);
+    const uint32_t base = w.cur << 6;   // < 2^31: the host caps the wide tree at 2^25 nodes
+    const float4 h0 = *reinterpret_cast<const float4*>(nb + base);
+    const uint4 h1 = *reinterpret_cast<const uint4*>(nb + (base + 16u));
+    const uint4 h2 = *reinterpret_cast<const uint4*>(nb + (base + 32u));
+    const uint4 ch = *reinterpret_cast<const uint4*>(nb + (base + 48u));
+    const float ax = h0.w * w.inv.x, ay = __uint_as_float(h1.x) * w.inv.y, az = __uint_as_float(h1.y) * w.inv.z;
+    const float dx = h0.x - w.o.x, dy = h0.y - w.o.y, dz = h0.z - w.o.z;
+    const float blx = __builtin_fmaf(dx, w.inv.x, -w.pad.x), bhx = __builtin_fmaf(dx, w.inv.x, w.pad.x);
+    const float bly = __builtin_fmaf(dy, w.inv.y, -w.pad.y), bhy = __builtin_fmaf(dy, w.inv.y, w.pad.y);
+    const float blz = __builtin_fmaf(dz, w.inv.z, -w.pad.z), bhz = __builtin_fmaf(dz, w.inv.z, w.pad.z);
+    const uint32_t nx = rt_bfi(w.mx, h2.y, h1.z), fx = rt_bfi(w.mx, h1.z, h2.y);
+    const uint32_t ny = rt_bfi(w.my, h2.z, h1.w), fy = rt_bfi(w.my, h1.w, h2.z);
+    const uint32_t nz = rt_bfi(w.mz, h2.w, h2.x), fz = rt_bfi(w.mz, h2.x, h2.w);
+    const float limit = ANY ? w.maxT : w.best.t;
     float k0, k1, k2, k3;
-    const f3 o = w.o, inv = w.inv;
-#define RT_SLOT(NX, NY, NZ, FX, FY, FZ, KEY)                                                             \
+#define RT_SLOT(UB, REF, KEY)                                                                               \
     {                                                                                                      \
-        float enx = (NX - o.x) * inv.x, exx = (FX - o.x) * inv.x;                                          \
-        float eny = (NY - o.y) * inv.y, exy = (FY - o.y) * inv.y;                                          \
-        float enz = (NZ - o.z) * inv.z, exz = (FZ - o.z) * inv.z;                                          \
-        float tentry = fmaxf(enx, fmaxf(eny, enz));                                                        \
-        float texit = fminf(exx, fminf(exy, exz));                                                         \
-        bool pass = (tentry <= texit);                                                                     \
-        if (ANY) {                                                                                         \
-            pass = pass && !(tentry > w.maxT) && !(fminf(exx + w.pad.x, fminf(exy + w.pad.y, exz + w.pad.z)) < 0.0f); \
-            KEY = pass ? tentry : RT_INF;                                                                  \
-        } else {                                                                                           \
-            float lo_ = fmaxf(enx - w.pad.x, fmaxf(eny - w.pad.y, enz - w.pad.z));                         \
-            float hi_ = fminf(exx + w.pad.x, fminf(exy + w.pad.y, exz + w.pad.z));                         \
-            pass = pass && !(lo_ > w.best.t) && !(hi_ < 0.0f);                                             \
-            KEY = pass ? lo_ : RT_INF;                                                                     \
-        }                                                                                                  \
+        float lo_ = fmaxf(__builtin_fmaf(UB(nx), ax, blx), fmaxf(__builtin_fmaf(UB(ny), ay, bly), __builtin_fmaf(UB(nz), az, blz))); \
+        float hi_ = fminf(__builtin_fmaf(UB(fx), ax, bhx), fminf(__builtin_fmaf(UB(fy), ay, bhy), __builtin_fmaf(UB(fz), az, bhz))); \
+        bool pass = (fmaxf(lo_, 0.0f) <= fminf(hi_, limit)) && (REF != RT_REF_EMPTY);                      \
+        KEY = pass ? lo_ : RT_INF;                                                                         \
     }
-    RT_SLOT(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, k0)
-    RT_SLOT(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, k1)
-    RT_SLOT(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, k2)
-    RT_SLOT(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, k3)
+    RT_SLOT(rt_ub0, ch.x, k0)
+    RT_SLOT(rt_ub1, ch.y, k1)
+    RT_SLOT(rt_ub2, ch.z, k2)
+    RT_SLOT(rt_ub3, ch.w, k3)
 #undef RT_SLOT
     uint32_t r0 = ch.x, r1 = ch.y, r2 = ch.z, r3 = ch.w;
     if (!ANY) {
@@ -431,7 +435,7 @@ __device__ __forceinline__ bool rt_wide_step(const DScene& S, Walk& w, TravStack
             float t, u, v;
             if (COUNT) c_tris++;
             if (rt_tri_test(S.tris + first + k, w.o, w.dir, t, u, v)) {
-                if (ANY) { if (t < w.maxT) { w.occluded = true; return true; } }
+                if (ANY) { if (t < w.maxT) { w.occluded = true; w.best.rank = first + k; return true; } }
                 else if (t < w.best.t || (t == w.best.t && (first + k) < w.best.rank)) {
                     w.best.t = t; w.best.u = u; w.best.v = v; w.best.rank = first + k;
                 }
@@ -469,7 +473,7 @@ __device__ __forceinline__ bool rt_vote_step(const DScene& S, Walk& w, bool busy
     float t, u, v;
     if (COUNT) c_tris++;
     if (rt_tri_eval_all(a, b, c, e, w.o, w.dir, t, u, v)) {
-        if (ANY) { if (t < w.maxT) { w.occluded = true; return true; } }
+        if (ANY) { if (t < w.maxT) { w.occluded = true; w.best.rank = tri; return true; } }
         else if (t < w.best.t || (t == w.best.t && tri < w.best.rank)) { w.best.t = t; w.best.u = u; w.best.v = v; w.best.rank = tri; }
     }
     if (left) { w.cur = RT_REF_LEAF | ((left - 1u) << 27) | (tri + 1u); return false; }
@@ -482,6 +486,7 @@ template <bool COUNT>
 __device__ __forceinline__ bool rt_closest_begin(const DScene& S, f3 o, f3 dir, int mode, Walk& w, uint32_t* spill2, uint32_t gstride,
                                                  uint32_t& cn, uint32_t& ct, uint32_t& cexact) {
     w.best.t = RT_FLT_MAX; w.best.u = 0; w.best.v = 0; w.best.rank = 0xFFFFFFFFu;
+    w.wide = false;
     if (S.root_ref == RT_REF_EMPTY) return true;
     // dir == (0,0,0) (what pathTrace shoots after a BSDF returned pdf 0 / wi 0, e.g. Materials.h:319-324): Dot(n, dir)
     // is 0 for every triangle, so Triangle::rayIntersect rejects all of them (Geometry.h:118) -- a miss, whatever
@@ -504,6 +509,7 @@ __device__ __forceinline__ bool rt_visible_begin(const DScene& S, f3 p1, f3 p2, 
     dir = norm3(dir);
     f3 o = p1 + (dir * RT_EPSILON);
     visible = true;
+    w.wide = false;
     if (S.root_ref == RT_REF_EMPTY) return true;
     f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
     const bool moderate = rt_ray_is_moderate(o, dir);
@@ -513,6 +519,32 @@ __device__ __forceinline__ bool rt_visible_begin(const DScene& S, f3 p1, f3 p2, 
     visible = (mode == 0 && moderate) ? rt_walk_exact<true, COUNT>(S, o, dir, maxT, dummy, spill2, gstride, cn, ct)
                         : rt_walk_reference<true, COUNT>(S, o, dir, maxT, dummy, spill2, gstride, cn, ct);
     return true;
+}
+
+// ---- the check that makes the conservative wide walk exact (see rt_node_eval).  Called once per item, on its final answer,
+// before it is retired: the reported triangle's gate box must pass upstream's own box test for this ray (any hit: with the
+// `tentry > maxT` rule of traverseVisible, Geometry.h:477).  An earlier, since replaced candidate needs no check: it only ever
+// culled what lies beyond it.  If the check fails the answer is recomputed by rt_walk_exact, which enters a subtree only
+// through upstream's test on upstream's boxes.
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ void rt_settle(const DScene& S, Walk& w, bool& visible, uint32_t* spill2, uint32_t gstride,
+                                          uint32_t& cn, uint32_t& ct, uint32_t& crefused) {
+    if (!w.wide) return;
+    w.wide = false;
+    if (ANY ? visible : !(w.best.t < RT_FLT_MAX)) return;   // nothing was accepted
+    const uint32_t rank = w.best.rank < S.n_tris ? w.best.rank : 0u;   // never read outside the array, whatever the walk left here
+    const float4* g = reinterpret_cast<const float4*>(S.gate + rank);
+    const float4 a = g[0], b = g[1];
+    float tb;
+    bool ok = rt_box_exact(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), w.o, w.inv, tb) && rank == w.best.rank;
+    if (ANY) ok = ok && !(tb > w.maxT);
+    if (ok) return;
+    if (COUNT) crefused++;
+    if (ANY) { HitRec dummy; visible = rt_walk_exact<true, COUNT>(S, w.o, w.dir, w.maxT, dummy, spill2, gstride, cn, ct); }
+    else {
+        w.best.t = RT_FLT_MAX; w.best.u = 0; w.best.v = 0; w.best.rank = 0xFFFFFFFFu;
+        rt_walk_exact<false, COUNT>(S, w.o, w.dir, 0.0f, w.best, spill2, gstride, cn, ct);
+    }
 }
 
 // ---- persistent traversal with lane refill (Aila & Laine's "persistent while-while" idea at wave64 width).
@@ -550,8 +582,9 @@ template <bool ANY, bool COUNT, class Job, class Source>
 __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, Source& src, int mode, TravStack& st, uint32_t* spill2,
                                                    uint32_t gstride, uint32_t& cn, uint32_t& ct, uint32_t& cx, DCounters* counters) {
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t c_slots = 0, c_busy = 0, c_mine = 0, c_max = 0;
+    uint32_t c_slots = 0, c_busy = 0, c_mine = 0, c_max = 0, c_refused = 0;
     Walk w;
+    w.wide = false;
     uint32_t item = 0;
     bool busy = false, done = false, visible = true;
     uint32_t pb = 0, pe = 0;   // the wave's pool of granted items (wave-uniform)
@@ -560,7 +593,7 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
         unsigned long long idle = __ballot(!busy);
         uint32_t nidle = (uint32_t)__popcll(idle);
         if (drained ? (nidle == 64u) : (nidle >= (uint32_t)(ANY ? RT_REFILL_IDLE_ANY : RT_REFILL_IDLE))) {
-            if (done) { job.retire(item, w, visible); done = false; }
+            if (done) { rt_settle<ANY, COUNT>(S, w, visible, spill2, gstride, cn, ct, c_refused); job.retire(item, w, visible); done = false; }
             if (drained) break;
             if (pb >= pe) {
                 if (!src.next(pb, pe)) { drained = true; if (RT_TAIL_STEAL) break; continue; }
@@ -615,12 +648,12 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
                     const float mt_ = rt_shfl_f(w.maxT, from);
                     const float bt_ = rt_shfl_f(w.best.t, from), bu_ = rt_shfl_f(w.best.u, from), bv_ = rt_shfl_f(w.best.v, from);
                     const uint32_t br_ = (uint32_t)__shfl((int)w.best.rank, (int)from);
-                    const uint32_t sx_ = (uint32_t)__shfl((int)w.sx, (int)from), sy_ = (uint32_t)__shfl((int)w.sy, (int)from), sz_ = (uint32_t)__shfl((int)w.sz, (int)from);
+                    const uint32_t sx_ = (uint32_t)__shfl((int)w.mx, (int)from), sy_ = (uint32_t)__shfl((int)w.my, (int)from), sz_ = (uint32_t)__shfl((int)w.mz, (int)from);
                     const uint32_t it_ = (uint32_t)__shfl((int)item, (int)from), cur_ = (uint32_t)__shfl((int)give, (int)from);
                     if (thief) {
                         w.o = o_; w.dir = d_; w.inv = i_; w.pad = p_; w.maxT = mt_;
                         w.best.t = bt_; w.best.u = bu_; w.best.v = bv_; w.best.rank = br_;
-                        w.sx = sx_; w.sy = sy_; w.sz = sz_; w.cur = cur_; w.sp = 0; w.occluded = false;
+                        w.mx = sx_; w.my = sy_; w.mz = sz_; w.cur = cur_; w.sp = 0; w.occluded = false; w.wide = true;
                         item = it_; busy = true; visible = true;
                         if (COUNT) c_mine = 0;
                     }
@@ -634,15 +667,18 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
             }
         }
         // results that were never part of a split retire together
-        if (done && !((split >> lane) & 1ULL)) { job.retire(item, w, visible); done = false; }
+        if (done && !((split >> lane) & 1ULL)) { rt_settle<ANY, COUNT>(S, w, visible, spill2, gstride, cn, ct, c_refused); job.retire(item, w, visible); done = false; }
         unsigned long long hm = __ballot(done);
         while (hm) {
             const uint32_t leader = (uint32_t)__ffsll((long long)hm) - 1u;
             const uint32_t it = (uint32_t)__shfl((int)item, (int)leader);
             const unsigned long long same = __ballot(done && item == it);
             if (ANY) {
-                const bool vis = __ballot(done && item == it && !visible) == 0ULL;
-                if (lane == leader) visible = vis;
+                const unsigned long long occ = __ballot(done && item == it && !visible);   // parts that found a blocker
+                if (occ) {
+                    const uint32_t r2 = (uint32_t)__shfl((int)w.best.rank, (int)((uint32_t)__ffsll((long long)occ) - 1u));
+                    if (lane == leader) { visible = false; w.best.rank = r2; }   // rt_settle checks that blocker's gate box
+                }
             } else {
                 unsigned long long rest = same & ~(1ULL << leader);
                 while (rest) {
@@ -653,7 +689,7 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
                     rest &= rest - 1ULL;
                 }
             }
-            if (lane == leader) job.retire(item, w, visible);
+            if (lane == leader) { w.wide = true; rt_settle<ANY, COUNT>(S, w, visible, spill2, gstride, cn, ct, c_refused); job.retire(item, w, visible); }
             hm &= ~same;
         }
     }
@@ -661,6 +697,7 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
         atomicAdd(ANY ? &counters->any_slots : &counters->slots, (unsigned long long)c_slots);
         atomicAdd(ANY ? &counters->any_busy : &counters->busy, (unsigned long long)c_busy);
         atomicMax(ANY ? &counters->any_max_steps : &counters->max_steps, (unsigned long long)c_max);
+        if (c_refused) atomicAdd(ANY ? &counters->any_refused : &counters->refused, (unsigned long long)c_refused);
     }
 }
 
@@ -671,6 +708,8 @@ __device__ __forceinline__ void rt_closest(const DScene& S, f3 o, f3 dir, int mo
     Walk w;
     if (!rt_closest_begin<COUNT>(S, o, dir, mode, w, spill2, gstride, cn, ct, cexact))
         while (!rt_wide_step<false, COUNT>(S, w, st, cn, ct)) {}
+    bool unused = true; uint32_t refused = 0;
+    rt_settle<false, COUNT>(S, w, unused, spill2, gstride, cn, ct, refused);
     best = w.best;
 }
 
@@ -682,5 +721,8 @@ __device__ __forceinline__ bool rt_visible(const DScene& S, f3 p1, f3 p2, int mo
     bool visible;
     if (rt_visible_begin<COUNT>(S, p1, p2, mode, w, visible, spill2, gstride, cn, ct, cexact)) return visible;
     while (!rt_wide_step<true, COUNT>(S, w, st, cn, ct)) {}
-    return !w.occluded;
+    visible = !w.occluded;
+    uint32_t refused = 0;
+    rt_settle<true, COUNT>(S, w, visible, spill2, gstride, cn, ct, refused);
+    return visible;
 }

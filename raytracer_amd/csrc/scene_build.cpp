@@ -189,13 +189,13 @@ struct Collapser {
         n.child[k] = ref;
     }
     static DNode4 empty_node() {
-        // an unused child slot carries a NaN box: every slab product is NaN, `tentry <= texit` is false, and the walk
-        // needs no separate "slot in use" test
+        // an unused child slot carries the empty box (lo = +inf, hi = -inf): for a finite non-zero 1/dir every entry distance
+        // is +inf and every exit distance -inf, the slot fails by itself and the walk needs no separate "slot in use" test
         DNode4 n; memset(&n, 0, sizeof(n));
-        const float qnan = std::numeric_limits<float>::quiet_NaN();
+        const float inf = std::numeric_limits<float>::infinity();
         for (int k = 0; k < 4; k++) {
             n.child[k] = RT_REF_EMPTY;
-            n.lox[k] = n.loy[k] = n.loz[k] = n.hix[k] = n.hiy[k] = n.hiz[k] = qnan;
+            n.lox[k] = n.loy[k] = n.loz[k] = inf; n.hix[k] = n.hiy[k] = n.hiz[k] = -inf;
         }
         return n;
     }
