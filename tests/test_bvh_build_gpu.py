@@ -98,3 +98,48 @@ def test_full_size_bathroom_build_and_time():
     rays = scenes.bounce_rays(s, 1 << 20, 3)
     assert np.array_equal(h.traverse(rays).view(np.uint8), d.traverse(rays).view(np.uint8))
     h.close(); d.close()
+
+
+@pytest.mark.parametrize("make", [
+    lambda: scenes.cornell(64, 64),
+    lambda: scenes.random_soup(5000, seed=9),
+    lambda: scenes.axis_aligned_grid(7),
+    lambda: scenes.interior("bathroom", 0.1, 320, 180),
+    lambda: scenes.random_soup(1, seed=2),
+], ids=["cornell", "soup", "lattice", "bathroom", "one-triangle"])
+def test_walk_nodes_bound_what_they_stand_for(make):
+    """The 64-B nodes the kernels read (rt_scene_debug_walk_nodes) against the float tree (rt_scene_debug_wide_nodes): same
+    children; an inner child's grid box contains the reference node's box, a leaf slot's grid box contains its triangles'
+    vertices, both within one grid step; unused slots are marked in the child word; every triangle's gate box is its leaf
+    slot's box in the float tree (what upstream's rayAABB is evaluated on)."""
+    s = make()
+    sc = api.Scene(s)
+    wide = sc.wide_nodes()
+    q, gate = sc.walk_nodes()
+    order = sc.leaf_order()
+    v = s.verts[order][:, :, :3].astype(np.float64)            # triangles in DFS leaf order
+    assert (q["child"] == wide["child"]).all()
+    EMPTY, LEAF = 0xFFFFFFFF, 0x80000000
+    org, scale = q["org"].astype(np.float64), q["scale"].astype(np.float64)
+    seen = np.zeros(len(order), bool)
+    for k in range(4):
+        ref = q["child"][:, k]
+        used = ref != EMPTY
+        leaf = used & ((ref & LEAF) != 0)
+        inner = used & ~leaf
+        glo = org + q["lo"][:, :, k] * scale                   # (nodes, 3)
+        ghi = org + q["hi"][:, :, k] * scale
+        flo, fhi = wide["box"][:, 0:3, k].astype(np.float64), wide["box"][:, 3:6, k].astype(np.float64)
+        assert (glo[inner] <= flo[inner]).all() and (ghi[inner] >= fhi[inner]).all()
+        step = np.maximum(scale, 0)
+        assert (flo[inner] - glo[inner] <= step[inner]).all() and (ghi[inner] - fhi[inner] <= step[inner]).all()
+        for i in np.nonzero(leaf)[0]:
+            first, cnt = int(ref[i] & 0x07FFFFFF), int((ref[i] >> 27) & 15) + 1
+            tv = v[first:first + cnt].reshape(-1, 3)
+            assert (glo[i] <= tv.min(0)).all() and (ghi[i] >= tv.max(0)).all(), (i, k)
+            assert (tv.min(0) - glo[i] <= step[i]).all() and (ghi[i] - tv.max(0) <= step[i]).all(), (i, k)
+            assert (gate["lo"][first:first + cnt] == wide["box"][i, 0:3, k]).all() and (gate["hi"][first:first + cnt] == wide["box"][i, 3:6, k]).all()
+            assert not seen[first:first + cnt].any()
+            seen[first:first + cnt] = True
+    assert seen.all(), "a triangle without a leaf slot"
+    sc.close()

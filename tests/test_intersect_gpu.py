@@ -6,7 +6,7 @@ import pytest
 import orc
 from raytracer_amd import api, scenes
 from raytracer_amd.abi import HIT_DTYPE
-from util import GOLDEN_SCENES, assert_hits_bitexact, axis_rays, load_golden
+from util import GOLDEN_SCENES, aimed_rays, assert_hits_bitexact, axis_rays, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -282,4 +282,36 @@ def test_cull_slack_holds_for_far_origins_grazing_and_near_axis_rays():
         assert_hits_bitexact(wide[k], r.traverse(rays[k]), "strained rays vs compiled reference", nan_payload_free=True)
         assert np.array_equal(v0[k], r.visible(segs[k]))
         r.close()
+    sc.close()
+
+
+@pytest.mark.parametrize("make", [
+    lambda: scenes.cornell(256, 256),
+    lambda: scenes.random_soup(3000, seed=5),
+    lambda: scenes.axis_aligned_grid(6),
+    lambda: scenes.interior("bathroom", 0.06, 320, 180),
+], ids=["cornell", "soup", "lattice", "bathroom"])
+def test_answers_refused_by_the_gate_box_are_recomputed_exactly(make):
+    """The wide walk culls with quantised, padded boxes only; upstream's candidate set ("every ancestor box passes rayAABB",
+    Geometry.h:441-490) is restored by testing the reported hit's gate box with upstream's expression and walking the ray again
+    with the exact walk when that test fails.  Rays aimed at vertices and edges put hits on the surface of their leaf's box:
+    the counters must show that refusals happen on these rays (the path under test runs), and every answer must equal the
+    oracle's and the reference-order walk's bit for bit."""
+    s = make()
+    o, sc = orc.OracleScene(s), api.Scene(s)
+    sc.counters_enable(True)
+    n = 1 << 20
+    rays, segs = aimed_rays(s, n)
+    sc.counters()
+    got = sc.traverse(rays, 0)
+    refused = sc.counters()["gate_refused"]
+    vis = sc.visible(segs, 0)
+    any_refused = sc.counters()["any_gate_refused"]
+    assert_hits_bitexact(got, sc.traverse(rays, 1), s.name + " wide vs reference-order, aimed rays")
+    assert (vis == sc.visible(segs, 1)).all()
+    k = 200_000
+    assert_hits_bitexact(got[:k], o.traverse(rays[:k], threads=8), s.name + " wide vs oracle, aimed rays")
+    assert (vis[:k] == o.visible(segs[:k], threads=8)).all()
+    assert refused > 0, "no closest-hit answer was refused: the aimed rays no longer reach rt_settle's fallback"
+    print(s.name, "refused", refused, "of", n, "closest;", any_refused, "any-hit")
     sc.close()

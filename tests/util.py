@@ -71,3 +71,23 @@ def hits_digest(hits, vis=None):
     if vis is not None:
         h.update(np.packbits(np.asarray(vis, np.uint8)).tobytes())
     return h.hexdigest()
+
+
+def aimed_rays(s, n, seed=7):
+    """Rays aimed at triangle vertices, edge points and interior points from origins around the scene, and the segments that
+    run through those points to twice the distance: hits that sit on the surface of their leaf's box, where the conservative
+    wide walk's answer is most often refused by the gate test (rt_settle) and recomputed by the exact walk."""
+    rng = np.random.default_rng(seed)
+    v = s.verts[:, :, :3].astype(np.float32)
+    tri = rng.integers(0, len(v), n)
+    w = rng.dirichlet([1, 1, 1], n).astype(np.float32)
+    kind = rng.integers(0, 3, n)
+    w[kind == 0] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, int((kind == 0).sum()))]
+    e = np.nonzero(kind == 1)[0]
+    w[e, rng.integers(0, 3, len(e))] = 0
+    w[e] /= w[e].sum(1, keepdims=True)
+    target = (v[tri] * w[:, :, None]).sum(1).astype(np.float32)
+    lo, hi = v.reshape(-1, 3).min(0), v.reshape(-1, 3).max(0)
+    o = rng.uniform(lo - 0.2 * (hi - lo), hi + 0.2 * (hi - lo), (n, 3)).astype(np.float32)
+    d = (target - o).astype(np.float32)
+    return np.concatenate([o, d], 1), np.concatenate([o, o + 2 * d], 1).astype(np.float32)
