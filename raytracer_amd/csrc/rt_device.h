@@ -316,6 +316,7 @@ struct Walk {
     float maxT;        // any hit
     HitRec best;       // closest hit so far; any hit: best.rank = the blocker that was found
     uint32_t cur, sp;
+    uint32_t pend;     // rt_vote_step: the leaf set aside while the lane walks on (RT_REF_EMPTY: none)
     uint32_t mx, my, mz;   // all ones where 1/dir is negative on that axis, else 0: picks a node's hi planes as the near planes
     bool occluded;
     bool wide;         // this item went through the 4-wide walk: its answer still has to pass rt_settle
@@ -327,7 +328,7 @@ __device__ __forceinline__ void rt_walk_init(const DScene& S, Walk& w, f3 o, f3 
     w.pad = mk3(delta * fabsf(inv.x), delta * fabsf(inv.y), delta * fabsf(inv.z));
     w.maxT = maxT;
     w.mx = inv.x < 0.0f ? 0xFFFFFFFFu : 0u; w.my = inv.y < 0.0f ? 0xFFFFFFFFu : 0u; w.mz = inv.z < 0.0f ? 0xFFFFFFFFu : 0u;
-    w.cur = S.root_ref; w.sp = 0; w.occluded = false; w.wide = true;
+    w.cur = S.root_ref; w.sp = 0; w.pend = RT_REF_EMPTY; w.occluded = false; w.wide = true;
 }
 // Box tests of one 4-wide node: pushes the passing children but the nearest, which becomes w.cur (returns true).
 //
@@ -451,11 +452,54 @@ __device__ __forceinline__ bool rt_wide_step(const DScene& S, Walk& w, TravStack
 // lanes standing in a leaf -- whichever serves more lanes per instruction; the others wait a step.
 // All 64 lanes call it (busy = this lane holds a walk).  Returns true when this lane's walk is over.
 #ifndef RT_VOTE_NUM
-#define RT_VOTE_NUM 3    // nodes go when (lanes on a node) * RT_VOTE_NUM >= (lanes in a leaf) * RT_VOTE_DEN; measured best near 1:1
-#define RT_VOTE_DEN 2
+#define RT_VOTE_NUM 1    // nodes go when (lanes on a node) * RT_VOTE_NUM >= (lanes with a leaf) * RT_VOTE_DEN.  With postponed leaves 1:1 is
+#define RT_VOTE_DEN 1    // best (3:2 -1.1 %, 1:2 -1.6 %; "triangles only once 16 / 24 / 32 lanes hold a leaf" -5 % / -4 % / -10 %)
 #endif
+// A lane that reaches a leaf does not stop walking: the leaf is set aside in w.pend and the lane pops on, so that it has work
+// for either kind of step -- box tests for its current node, one triangle of its postponed leaf (Aila & Laine's speculative
+// traversal).  What it costs: the nodes walked meanwhile were not culled by the hit the postponed leaf may hold.  A second
+// leaf met while one is postponed waits in w.cur until the first is done.
+#ifndef RT_POSTPONE
+#define RT_POSTPONE 1
+#endif
+__device__ __forceinline__ bool rt_ref_is_node(uint32_t r) { return !(r & RT_REF_LEAF); }
+__device__ __forceinline__ bool rt_ref_is_leaf(uint32_t r) { return (r & RT_REF_LEAF) && r != RT_REF_EMPTY; }
+template <bool ANY>
+__device__ __forceinline__ void rt_pop_or_none(Walk& w, TravStack& st) { if (!rt_pop<ANY>(w, st)) w.cur = RT_REF_EMPTY; }
+// cur is a node, a leaf that has to wait, or none; a leaf moves to pend as soon as pend is free
+template <bool ANY>
+__device__ __forceinline__ void rt_settle_refs(Walk& w, TravStack& st) {
+    if (rt_ref_is_leaf(w.cur) && w.pend == RT_REF_EMPTY) { w.pend = w.cur; rt_pop_or_none<ANY>(w, st); }
+}
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ bool rt_vote_step(const DScene& S, Walk& w, bool busy, TravStack& st, uint32_t& c_nodes, uint32_t& c_tris) {
+#if RT_POSTPONE
+    const bool innode = busy && rt_ref_is_node(w.cur);
+    const bool inleaf = busy && w.pend != RT_REF_EMPTY;
+    const uint32_t nl = (uint32_t)__popcll(__ballot(inleaf)), nn = (uint32_t)__popcll(__ballot(innode));
+    if (nn * (uint32_t)RT_VOTE_NUM >= nl * (uint32_t)RT_VOTE_DEN) {
+        if (!innode) return false;
+        if (COUNT) c_nodes++;
+        if (!rt_node_eval<ANY>(S, w, st)) rt_pop_or_none<ANY>(w, st);
+        rt_settle_refs<ANY>(w, st);
+        return w.cur == RT_REF_EMPTY && w.pend == RT_REF_EMPTY;
+    }
+    if (!inleaf) return false;
+    const uint32_t leaf = w.pend;
+    const uint32_t tri = leaf & RT_LEAF_FIRST_MASK, left = (leaf >> 27) & 15u;  // triangles left in the leaf after this one
+    const float4* q = reinterpret_cast<const float4*>(S.tris + tri);
+    float4 a = q[0], b = q[1], c = q[2], e = q[3];
+    float t, u, v;
+    if (COUNT) c_tris++;
+    if (rt_tri_eval_all(a, b, c, e, w.o, w.dir, t, u, v)) {
+        if (ANY) { if (t < w.maxT) { w.occluded = true; w.best.rank = tri; return true; } }
+        else if (t < w.best.t || (t == w.best.t && tri < w.best.rank)) { w.best.t = t; w.best.u = u; w.best.v = v; w.best.rank = tri; }
+    }
+    if (left) { w.pend = RT_REF_LEAF | ((left - 1u) << 27) | (tri + 1u); return false; }
+    w.pend = RT_REF_EMPTY;
+    rt_settle_refs<ANY>(w, st);
+    return w.cur == RT_REF_EMPTY && w.pend == RT_REF_EMPTY;
+#else
     const uint32_t cur = w.cur;
     const bool inleaf = busy && (cur & RT_REF_LEAF) != 0;
     const bool innode = busy && !(cur & RT_REF_LEAF);
@@ -478,6 +522,7 @@ __device__ __forceinline__ bool rt_vote_step(const DScene& S, Walk& w, bool busy
     }
     if (left) { w.cur = RT_REF_LEAF | ((left - 1u) << 27) | (tri + 1u); return false; }
     return !rt_pop<ANY>(w, st);
+#endif
 }
 
 // Scene::traverse (Scene.h:118), set-up half: returns true when the result is already known (w.best), false when
@@ -653,7 +698,8 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
                     if (thief) {
                         w.o = o_; w.dir = d_; w.inv = i_; w.pad = p_; w.maxT = mt_;
                         w.best.t = bt_; w.best.u = bu_; w.best.v = bv_; w.best.rank = br_;
-                        w.mx = sx_; w.my = sy_; w.mz = sz_; w.cur = cur_; w.sp = 0; w.occluded = false; w.wide = true;
+                        w.mx = sx_; w.my = sy_; w.mz = sz_; w.cur = cur_; w.sp = 0; w.pend = RT_REF_EMPTY; w.occluded = false; w.wide = true;
+                        if (RT_POSTPONE && rt_ref_is_leaf(w.cur)) { w.pend = w.cur; w.cur = RT_REF_EMPTY; }
                         item = it_; busy = true; visible = true;
                         if (COUNT) c_mine = 0;
                     }

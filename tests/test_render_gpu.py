@@ -230,20 +230,22 @@ def test_converged_render_relmse_cornell_256():
     assert r < 1e-3, f"relMSE {r}"
 
 
-@pytest.mark.parametrize("variant,fixture", [("bathroom", "film_bathroom240_32768.npy"), ("living-room", "film_livingroom240_32768.npy")])
-def test_converged_render_relmse_on_the_bench_workloads(variant, fixture):
+@pytest.mark.parametrize("variant,stem", [("bathroom", "film_bathroom240"), ("living-room", "film_livingroom240")])
+def test_converged_render_relmse_on_the_bench_workloads(variant, stem):
     """north_star image gate on the bench scenes themselves (configs 3-4: the default bathroom-class / living-room-class stand-ins,
-    1.1 M triangles, here at 240 x 135): relMSE < 1e-3 against the CPU render (oracle, 32768 spp, another seed;
+    1.1 M triangles, here at 240 x 135): relMSE < 1e-3 against the CPU render (oracle, M = 32768 or 65536 spp, another seed;
     tests/golden/make_film_golden_r2.py).  These interiors carry glass-to-light paths with a per-pixel relative variance
-    sigma^2 of about 10 (the test measures it from two GPU renders), so two independent 4096-spp films are ~5e-3 apart whoever
-    renders them: the bound is therefore checked where it is a statement about bias -- the GPU renders 65536 spp, which
-    leaves sigma^2 (1/65536 + 1/32768) ~ 5e-4 of noise -- and at 4096 spp the distance to the reference must be what the
-    measured variance predicts."""
-    path = os.path.join(GOLDEN, fixture)
-    if not os.path.exists(path):
-        pytest.skip(f"{fixture} has not been generated yet (tests/golden/make_film_golden_r2.py, about an hour of CPU)")
-    ref = np.load(path).astype(np.float64)
-    M, N = 32768, 65536
+    sigma^2 of 20-25 (the test measures it from two GPU renders), so two independent 4096-spp films are ~1e-2 apart whoever
+    renders them and the reference's own noise, sigma^2 / M, is most of the bound.  The bound is therefore checked where it
+    is a statement about bias: the GPU renders 262144 spp (sigma^2 (1/262144 + 1/M) ~ 7e-4 at M = 32768), the means must agree
+    to 5e-4, the same films binned 2 x 2 (a quarter of the noise, any bias intact) must be within 4e-4, and at 4096 spp the
+    distance to the reference must be what the measured variance predicts."""
+    have = [m for m in (65536, 32768) if os.path.exists(os.path.join(GOLDEN, f"{stem}_{m}.npy"))]
+    if not have:
+        pytest.skip(f"{stem}_*.npy has not been generated yet (tests/golden/make_film_golden_r2.py, about an hour of CPU)")
+    M = have[0]
+    ref = np.load(os.path.join(GOLDEN, f"{stem}_{M}.npy")).astype(np.float64)
+    N = 262144
     s = scenes.interior(variant, 1.0, 240, 135)
     sc = api.Scene(s)
     rt = api.RayTracer(sc)
@@ -260,11 +262,18 @@ def test_converged_render_relmse_on_the_bench_workloads(variant, fixture):
     got = film.astype(np.float64) / N
     r = rel_mse(got, ref)
     assert r < 1e-3, f"relMSE {r}"
-    assert abs(got.mean() / ref.mean() - 1) < 5e-3
+    assert abs(got.mean() / ref.mean() - 1) < 5e-4
+
+    def binned(a):
+        h, w = a.shape[0] // 2 * 2, a.shape[1] // 2 * 2
+        return a[:h, :w].reshape(h // 2, 2, w // 2, 2, 3).mean((1, 3))
+    rb = rel_mse(binned(got), binned(ref))
+    assert rb < 4e-4, f"relMSE of the 2 x 2 binned films {rb}"
     sigma2 = rel_mse(g4a, g4b) * 4096 / 2                                # relMSE of two independent n-spp films = 2 sigma^2 / n
     predicted = sigma2 * (1 / 4096 + 1 / M)
     r4 = rel_mse(g4a, ref)
-    assert 0.5 * predicted < r4 < 1.6 * predicted, (r4, predicted, sigma2)
+    assert 0.5 * predicted < r4 < 1.8 * predicted, (r4, predicted, sigma2)
+    print(variant, "M", M, "relMSE", r, "binned", rb, "sigma2", sigma2, "4096-spp relMSE", r4, "predicted", predicted)
 
 
 def test_specular_scene_matches_cpu_render_to_its_noise_floor():
