@@ -24,9 +24,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 L2_PEAK_GBS = 34500.0   # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
-NODE_BYTES, TRI_BYTES = 128, 64
+NODE_BYTES, TRI_BYTES = 64, 64   # the walk's quantised 4-wide node (round 1-2a: 128-B float nodes) and the triangle record
 # k_extend per ray besides node/triangle fetches: ray origin + direction (32) + flags / throughput (16) + hit write (16) + queue read/write (8)
-EXTEND_FIXED_BYTES = 72
+# + the gate box of the reported hit (32)
+EXTEND_FIXED_BYTES = 104
 PMC_FILE = os.path.join("profiles", "r02_pmc.json")   # written by tools/profile_round.sh from rocprofv3 --pmc runs of this script
 
 
@@ -228,10 +229,14 @@ def main():
                 "film_mean": film_mean, "film_median": film_median, "film_nonfinite_values": film_nan,
             },
             "roofline": {
-                # what limits the dominant kernel, by the PMC counters of this command (profiles/): VALU issue, not memory
-                "bound": "valu",
+                # what limits the dominant kernel: instruction issue, not HBM or MFMA.  By the PMC counters of this command (profiles/)
+                # VALU issue slots are full and the texture-address unit is busy 70 % of the time; by experiment
+                # the kernel's time follows the number of divergent vector-memory instructions per step
+                "bound": "issue",
+                "bound_is": "instruction issue (VALU slots + divergent vector-memory instructions through the TA), neither HBM nor MFMA: one more dwordx4 per node step "
+                            "costs +17 % of the kernel, 12 % more VALU instructions +3 %, fabric traffic is < 0.2 of the HBM peak",
                 "kernel": "k_extend<false,false,0> (closest-hit 4-wide BVH walk)",
-                # the SURVEY 8(d) figure: ALGORITHMIC bytes (every 128-B node and 64-B triangle fetch counted, cache hits included)
+                # the SURVEY 8(d) figure: ALGORITHMIC bytes (every 64-B node and 64-B triangle fetch counted, cache hits included)
                 # per launch / average launch duration by HIP events over the timed regions, against the HBM peak
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

@@ -349,6 +349,16 @@ __device__ inline DSlot d_make_slot(const GNode* __restrict__ nodes, int32_t chi
     s.bnode = child; s.count = 0u;
     return s;
 }
+// scene_build.cpp's Collapser::split_leaves
+__device__ inline int d_split_leaves(DSlot* slots, int ns) {
+    for (int i = 0; i < ns && ns < 4; i++) {
+        if (slots[i].bnode >= 0 || slots[i].count < 2u || slots[i].count > RT_LEAF_MAX) continue;
+        for (int k = ns; k > i + 1; k--) slots[k] = slots[k - 1];
+        slots[i + 1] = slots[i];
+        slots[i].count = 1u; slots[i + 1].first += 1u; slots[i + 1].count -= 1u; ns++;
+    }
+    return ns;
+}
 __device__ inline int d_gather(const GNode* __restrict__ nodes, const DWork& w, DSlot* slots) {
     int ns = 0;
     if (w.bnode < 0) {
@@ -359,7 +369,7 @@ __device__ inline int d_gather(const GNode* __restrict__ nodes, const DWork& w, 
             for (int k = 0; k < 3; k++) { s.lo[k] = w.lo[k]; s.hi[k] = w.hi[k]; }
             s.bnode = -1; s.first = w.first + b; s.count = e - b;
         }
-        return ns;
+        return d_split_leaves(slots, ns);
     }
     const GNode b = nodes[w.bnode];
     slots[ns++] = d_make_slot(nodes, b.left, b.lo, b.hi);
@@ -374,7 +384,7 @@ __device__ inline int d_gather(const GNode* __restrict__ nodes, const DWork& w, 
         for (int i = ns; i > pick + 1; i--) slots[i] = slots[i - 1];
         slots[pick] = l; slots[pick + 1] = r; ns++;
     }
-    return ns;
+    return d_split_leaves(slots, ns);
 }
 __device__ __forceinline__ bool d_slot_is_node(const DSlot& s) { return s.bnode >= 0 || s.count > RT_LEAF_MAX; }
 // pass 1: how many children of each wide node become wide nodes of the next level

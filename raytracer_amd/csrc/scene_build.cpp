@@ -208,7 +208,7 @@ struct Collapser {
                 const uint32_t b = (uint32_t)((uint64_t)w.count * p / parts), e = (uint32_t)((uint64_t)w.count * (p + 1) / parts);
                 slots[ns].box = w.box; slots[ns].bnode = -1; slots[ns].first = w.first + b; slots[ns].count = e - b; ns++;
             }
-            return ns;
+            return split_leaves(slots, ns);
         }
         slots[ns++] = make_slot(bn[w.bnode].left, bn[w.bnode].box);
         slots[ns++] = make_slot(bn[w.bnode].right, bn[w.bnode].box);
@@ -221,6 +221,18 @@ struct Collapser {
             const Slot l = make_slot(bn[e].left, bn[e].box), r = make_slot(bn[e].right, bn[e].box);
             for (int i = ns; i > pick + 1; i--) slots[i] = slots[i - 1];
             slots[pick] = l; slots[pick + 1] = r; ns++;
+        }
+        return split_leaves(slots, ns);
+    }
+    // Slots that are still free go to the triangles of multi-triangle leaf slots, one triangle each, in slot order: the walk
+    // bounds every leaf slot by its own triangles (k_quantise), so a ray that misses one triangle of a pair no longer tests it.
+    // The parts keep the slot's reference box (the gate of their triangles).
+    static int split_leaves(Slot* slots, int ns) {
+        for (int i = 0; i < ns && ns < 4; i++) {
+            if (slots[i].bnode >= 0 || slots[i].count < 2 || slots[i].count > RT_LEAF_MAX) continue;
+            for (int k = ns; k > i + 1; k--) slots[k] = slots[k - 1];
+            slots[i + 1] = slots[i];
+            slots[i].count = 1; slots[i + 1].first += 1; slots[i + 1].count -= 1; ns++;
         }
         return ns;
     }

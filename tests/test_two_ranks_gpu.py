@@ -114,7 +114,7 @@ def test_bench_line_contract_one_gpu():
     assert b["n_gpus"] == 1 and b["steps"] == 2 and b["warmup"] == 1 and b["higher_is_better"] is True and b["vs_baseline"] is None
     assert b["unit"] == "Mrays/s" and b["dtype"] == "f32" and b["data"] == "synthetic" and "workload" in b["config"]
     rf = b["roofline"]
-    assert rf["bound"] == "valu" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["achieved"] > 0
+    assert rf["bound"] == "issue" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["achieved"] > 0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     # counter-derived figures are only printed for the batch shape they were measured on: this reduced scene has none
     assert rf["traffic"] is None and rf["ceilings"] is None
