@@ -51,7 +51,7 @@ def test_device_build_equals_host_build(make):
 
 
 def test_long_leaves_are_cut_the_same_way():
-    """More than 16 triangles whose centroids coincide cannot be split (Geometry.h:418's axis stays -1) and end up in one leaf;
+    """More than RT_LEAF_MAX (4) triangles whose centroids coincide cannot be split (Geometry.h:418's axis stays -1) and end up in one leaf;
     the wide tree cuts such a range into a small subtree of slots.  Host and device must cut alike."""
     rng = np.random.default_rng(6)
     s = scenes.random_soup(600, seed=8)
