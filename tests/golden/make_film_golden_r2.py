@@ -4,7 +4,7 @@ bathroom-class and living-room-class stand-ins (the default, bounded material mi
 and the diffuse Cornell box at 256x256.  The reference's Renderer.h cannot be built in this image (needs <Windows.h> / OIDN),
 so these films come from the CPU oracle (oracle/rt_oracle.c) -- "parity unpinned" as DESIGN section 5 says -- with an RNG seed
 the GPU tests do not use.  The interiors are not converged at 4096 spp (glass-to-light paths: per-pixel relative variance
-sigma^2 ~ 10, so two independent 4096-spp films are ~5e-3 apart); the reference therefore takes 32768 spp, and the GPU test
+sigma^2 ~ 10, so two independent 4096-spp films are ~5e-3 apart); the reference therefore takes 32768 spp and then 65536 spp, and the GPU test
 renders enough samples for the north-star bound to be a statement about bias, not noise.
     python tests/golden/make_film_golden_r2.py [threads]"""
 import os
@@ -21,27 +21,32 @@ from raytracer_amd import scenes  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 threads = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-JOBS = (("film_cornell256_4096", lambda: scenes.cornell(256, 256), 4096),
-        ("film_bathroom240_32768", lambda: scenes.interior("bathroom", 1.0, 240, 135), 32768),
-        ("film_livingroom240_32768", lambda: scenes.interior("living-room", 1.0, 240, 135), 32768))
-for name, make, spp in JOBS:
-    out = os.path.join(HERE, name + ".npy")
-    if os.path.exists(out):
+# (stem, scene, checkpoints): a film is written at every checkpoint (<stem>_<spp>.npy); the sum so far lives in /tmp, so a run
+# that was cut off, or a later run with a further checkpoint, goes on from there (same seed, consecutive sample indices)
+JOBS = (("film_cornell256", lambda: scenes.cornell(256, 256), (4096,)),
+        ("film_bathroom240", lambda: scenes.interior("bathroom", 1.0, 240, 135), (32768, 65536)),
+        ("film_livingroom240", lambda: scenes.interior("living-room", 1.0, 240, 135), (32768, 65536)))
+for stem, make, checkpoints in JOBS:
+    if all(os.path.exists(os.path.join(HERE, f"{stem}_{c}.npy")) for c in checkpoints):
         continue
     s = make()
     o = orc.OracleScene(s)
-    part_file = "/tmp/" + name + ".partial.npz"     # resumable: the sum so far and how many samples it holds
+    part_file = "/tmp/" + stem + ".partial.npz"
     film, done = np.zeros((s.height, s.width, 3), np.float64), 0
-    if os.path.exists(part_file):
-        z = np.load(part_file); film, done = z["film"], int(z["done"])
+    for cand in [part_file] + ["/tmp/%s_%d.partial.npz" % (stem, c) for c in checkpoints]:   # (the second form: this script's first version)
+        if os.path.exists(cand):
+            z = np.load(cand)
+            if int(z["done"]) > done:
+                film, done = z["film"], int(z["done"])
     t = time.time()
-    while done < spp:   # in slices: fp32 film sums stay short, progress is visible
-        k = min(1024, spp - done)
+    while done < checkpoints[-1]:   # in slices: fp32 film sums stay short, progress is visible
+        k = min(1024, min(c for c in checkpoints if c > done) - done)
         part, st = o.render(mode=0, spp=k, seed=987654321, first_sample=done, threads=threads)
         film += part
         done += k
         np.savez(part_file + ".tmp.npz", film=film, done=done); os.replace(part_file + ".tmp.npz", part_file)
-        print(name, done, "%.0fs" % (time.time() - t), flush=True)
-    assert np.isfinite(film).all()
-    np.save(out, (film / spp).astype(np.float32))
-    print(name, "done", film.mean() / spp, flush=True)
+        print(stem, done, "%.0fs" % (time.time() - t), flush=True)
+        if done in checkpoints:
+            assert np.isfinite(film).all()
+            np.save(os.path.join(HERE, f"{stem}_{done}.npy"), (film / done).astype(np.float32))
+            print(stem, done, "written", film.mean() / done, flush=True)
