@@ -315,3 +315,25 @@ def test_answers_refused_by_the_gate_box_are_recomputed_exactly(make):
     assert refused > 0, "no closest-hit answer was refused: the aimed rays no longer reach rt_settle's fallback"
     print(s.name, "refused", refused, "of", n, "closest;", any_refused, "any-hit")
     sc.close()
+
+
+@pytest.mark.parametrize("scale,shift", [(1e-12, 0.0), (1e12, 0.0), (1.0, 3e5), (1e-3, 40.0)], ids=["tiny", "huge", "far-from-origin", "small-and-offset"])
+def test_quantised_nodes_on_scaled_and_shifted_scenes(scale, shift):
+    """The walk's nodes put child boxes on a 256-step grid whose step is a power of two taken from the node's extent: scenes a
+    factor 1e12 smaller or larger than the fixtures, or far from the origin (where a coordinate's ulp approaches the size of a
+    triangle), must give the oracle's answers bit for bit, and a flat scene (zero extent on an axis: step 0) too."""
+    base = scenes.random_soup(4000, seed=12)
+    v = base.verts.copy()
+    v[:, :, :3] = (v[:, :, :3] * np.float32(scale) + np.float32(shift)).astype(np.float32)
+    v[:200, :, 2] = np.float32(shift)                      # a flat patch: leaves and nodes without extent along z
+    s = scenes.SceneData("scaled", v, base.tri_mat.copy(), base.materials, base.textures)
+    c = np.float32(shift)
+    scenes.set_camera(s, (c, c, c + 12 * scale), (c, c, c), (0, 1, 0), 45.0, 64, 64)
+    o, sc = orc.OracleScene(s), api.Scene(s)
+    rays, segs = aimed_rays(s, 150_000, seed=3)
+    rays = np.concatenate([rays, scenes.primary_rays(s, 20_000, 1), axis_rays(s, 10_000)])
+    assert_hits_bitexact(sc.traverse(rays, 0), o.traverse(rays, threads=8), f"scaled x{scale} +{shift}")
+    assert (sc.visible(segs, 0) == o.visible(segs, threads=8)).all()
+    q, _ = sc.walk_nodes()
+    assert np.isfinite(q["scale"]).all() and (q["scale"] >= 0).all()
+    sc.close()

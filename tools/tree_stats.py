@@ -17,3 +17,21 @@ print(name, s.ntris, "triangles", len(w), "nodes; used slots per node:", np.binc
 full = used.sum(1) == 4
 two = (leaf & (cnt == 2))
 print("nodes with a free slot and a 2-triangle leaf:", int(((~full) & two.any(1)).sum()), "; 2-triangle leaf slots in full nodes:", int(two[full].sum()), "of", int(two.sum()))
+# depth of the wide tree: nodes are numbered level by level, parents before children
+depth = np.zeros(len(w), np.int32)
+for k in range(4):
+    pass
+inner = used & ~leaf
+order_ok = True
+for i in range(len(w)):
+    for k in range(4):
+        if inner[i, k]:
+            depth[ref[i, k]] = depth[i] + 1
+ld = np.repeat(depth[:, None], 4, 1)[leaf]
+area = 2 * ((w["box"][:, 3] - w["box"][:, 0]) * (w["box"][:, 4] - w["box"][:, 1]) + (w["box"][:, 4] - w["box"][:, 1]) * (w["box"][:, 5] - w["box"][:, 2]) + (w["box"][:, 3] - w["box"][:, 0]) * (w["box"][:, 5] - w["box"][:, 2]))
+la = area[leaf]
+print("wide tree depth: max", int(depth.max()), "mean over leaf slots", float(ld.mean()), "area-weighted", float((ld * la).sum() / la.sum()), "; log4(nodes)", np.log(len(w)) / np.log(4))
+print("leaf-slot depth histogram:", np.bincount(ld).tolist())
+root_area = area[0][used[0]].max()
+# SAH-style expected visits for a random ray: sum over inner child slots of area / root area (+1 for the root)
+print("expected node visits (sum of inner-slot areas / scene area):", 1 + float(area[inner].sum()) / float(root_area), " expected leaf-slot visits:", float(la.sum()) / float(root_area))
