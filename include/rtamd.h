@@ -93,7 +93,7 @@ typedef struct {
 
 typedef struct {
     uint64_t closest_rays, any_rays;        /* rays issued (Scene::traverse / Scene::visible equivalents) */
-    uint64_t nodes_visited, tris_tested;    /* closest-hit walks: wide-node fetches (128 B each) and triangle-record fetches (64 B each) */
+    uint64_t nodes_visited, tris_tested;    /* closest-hit walks: wide-node fetches (64 B each: the quantised nodes) and triangle-record fetches (64 B each) */
     uint64_t exact_path_rays;               /* rays routed through the reference-order fallback walk */
     uint64_t any_nodes_visited, any_tris_tested;  /* the same two counts for any-hit (Scene::visible) walks */
     uint64_t lane_slots, lane_busy;         /* closest-hit walks: 64 x wave traversal steps, and how many of those lanes held a ray */
@@ -126,7 +126,7 @@ int rt_scene_set_camera(rt_scene* scene, const rt_camera* cam);
 int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
 /* DFS leaf order of the reference tree (triangle indices), for structural parity checks. */
 int rt_scene_leaf_order(const rt_scene* scene, uint32_t* out_n_tris);
-/* The flattened 4-wide tree (wide_nodes x 128 B: lox[4] loy[4] loz[4] hix[4] hiy[4] hiz[4] child[4] pad[4]) as it sits in
+/* The flattened 4-wide tree as the builders produce it (wide_nodes x 128 B: lox[4] loy[4] loz[4] hix[4] hiy[4] hiz[4] child[4] pad[4]) as it sits in
  * device memory, for structural checks (device-side build == host build). */
 int rt_scene_debug_wide_nodes(rt_scene* scene, void* out, size_t max_nodes);
 /* The same tree as the traversal kernels read it (wide_nodes x 64 B: org[3] scale[3] lox loy loz hix hiy hiz child[4]; child k's box

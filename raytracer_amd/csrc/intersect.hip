@@ -350,7 +350,7 @@ extern "C" int rt_scene_get_info(const rt_scene* s, rt_scene_info* o) {
     return RT_OK;
 }
 
-// The 4-wide tree as the kernels read it (128 B per node), copied back from device memory: lets a test compare the
+// The 4-wide tree as the builders produce it (128 B per node, float boxes), copied back from device memory: lets a test compare the
 // device-side collapse with the host's, node for node.
 extern "C" int rt_scene_debug_wide_nodes(rt_scene* s, void* out, size_t max_nodes) {
     if (!s || !out) { rt_set_error("rt_scene_debug_wide_nodes: NULL argument"); return RT_ERR_INVALID; }
