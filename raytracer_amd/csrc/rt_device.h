@@ -478,19 +478,29 @@ __device__ __forceinline__ bool rt_vote_step(const DScene& S, Walk& w, bool busy
     const bool inleaf = busy && w.pend != RT_REF_EMPTY;
     const uint32_t nl = (uint32_t)__popcll(__ballot(inleaf)), nn = (uint32_t)__popcll(__ballot(innode));
     if (nn * (uint32_t)RT_VOTE_NUM >= nl * (uint32_t)RT_VOTE_DEN) {
-        if (!innode) return false;
+#ifdef RT_DBG_WAVESTEPS
         if (COUNT) c_nodes++;
+#endif
+        if (!innode) return false;
+#ifndef RT_DBG_WAVESTEPS
+        if (COUNT) c_nodes++;
+#endif
         if (!rt_node_eval<ANY>(S, w, st)) rt_pop_or_none<ANY>(w, st);
         rt_settle_refs<ANY>(w, st);
         return w.cur == RT_REF_EMPTY && w.pend == RT_REF_EMPTY;
     }
+#ifdef RT_DBG_WAVESTEPS
+    if (COUNT) c_tris++;
+#endif
     if (!inleaf) return false;
     const uint32_t leaf = w.pend;
     const uint32_t tri = leaf & RT_LEAF_FIRST_MASK, left = (leaf >> 27) & 15u;  // triangles left in the leaf after this one
     const float4* q = reinterpret_cast<const float4*>(S.tris + tri);
     float4 a = q[0], b = q[1], c = q[2], e = q[3];
     float t, u, v;
+#ifndef RT_DBG_WAVESTEPS
     if (COUNT) c_tris++;
+#endif
     if (rt_tri_eval_all(a, b, c, e, w.o, w.dir, t, u, v)) {
         if (ANY) { if (t < w.maxT) { w.occluded = true; w.best.rank = tri; return true; } }
         else if (t < w.best.t || (t == w.best.t && tri < w.best.rank)) { w.best.t = t; w.best.u = u; w.best.v = v; w.best.rank = tri; }

@@ -1,5 +1,6 @@
 """Where the lanes of the traversal kernels go: of all lane-slots (64 x wave steps), how many held a walk (busy) and how many
-did a node or a triangle that step (served).   python tools/lane_stats.py [spp]"""
+did a node or a triangle that step (served).   python tools/lane_stats.py [spp]
+With RT_LIB pointing at a library built with -DRT_DBG_WAVESTEPS the node / triangle counts are 64 x the wave steps of each kind."""
 import os, sys
 import numpy as np
 import torch  # noqa: F401
