@@ -160,7 +160,11 @@ __global__ void k_quantise(const DNode4* __restrict__ in, uint32_t n, const DTri
     for (int k = 0; k < 4; k++) {
         const uint32_t ref = nd.child[k];
         lo[0][k] = nd.lox[k]; lo[1][k] = nd.loy[k]; lo[2][k] = nd.loz[k]; hi[0][k] = nd.hix[k]; hi[1][k] = nd.hiy[k]; hi[2][k] = nd.hiz[k];
+#ifndef RT_EXP_LOOSE_LEAVES   // (experiment switch: leaf slots keep their reference box, to tell the tight boxes' share of the gain from the nodes')
         if (ref != RT_REF_EMPTY && (ref & RT_REF_LEAF)) {
+#else
+        if (false) {
+#endif
             const uint32_t first = ref & RT_LEAF_FIRST_MASK, cnt = ((ref >> 27) & 15u) + 1u;
             for (int a = 0; a < 3; a++) { lo[a][k] = RT_INF; hi[a][k] = -RT_INF; }
             for (uint32_t t = 0; t < cnt; t++) {
