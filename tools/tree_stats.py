@@ -35,3 +35,21 @@ print("leaf-slot depth histogram:", np.bincount(ld).tolist())
 root_area = area[0][used[0]].max()
 # SAH-style expected visits for a random ray: sum over inner child slots of area / root area (+1 for the root)
 print("expected node visits (sum of inner-slot areas / scene area):", 1 + float(area[inner].sum()) / float(root_area), " expected leaf-slot visits:", float(la.sum()) / float(root_area))
+# where triangle tests go for random rays: a leaf slot is entered in proportion to the area of its (tight) box, and then tests all its
+# triangles; a triangle is hit in proportion to twice its own area.  waste = tests per hit, by triangle size.
+order = sc.leaf_order()
+v = s.verts[order][:, :, :3].astype(np.float64)
+tri_area = 0.5 * np.linalg.norm(np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]), axis=1)
+tests = np.zeros(len(v)); slot_of = np.zeros(len(v), np.int64)
+for i, k in zip(*np.nonzero(leaf)):
+    r = int(ref[i, k]); first, c = r & 0x07FFFFFF, ((r >> 27) & 15) + 1
+    tv = v[first:first + c].reshape(-1, 3)
+    ext = tv.max(0) - tv.min(0)
+    a = 2 * (ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2])
+    tests[first:first + c] = a
+print("random rays: triangle tests per true hit =", tests.sum() / (2 * tri_area).sum())
+o2 = np.argsort(-tests)
+cum = np.cumsum(tests[o2]) / tests.sum()
+for frac in (0.0001, 0.001, 0.01, 0.1):
+    n = max(1, int(len(v) * frac))
+    print(f"  the {n} triangles ({frac:.2%}) with the largest slot boxes take {cum[n - 1]:.1%} of all tests; their own hit share {(2 * tri_area[o2[:n]]).sum() / (2 * tri_area).sum():.1%}")
