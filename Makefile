@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CSRC = raytracer_amd/csrc
-SRCS = $(CSRC)/scene_build.cpp $(CSRC)/bvh_build.hip $(CSRC)/intersect.hip $(wildcard $(CSRC)/render.hip)
+SRCS = $(CSRC)/scene_build.cpp $(CSRC)/bvh_build.hip $(CSRC)/intersect.hip $(CSRC)/walk_tree.hip $(wildcard $(CSRC)/render.hip)
 HDRS = $(wildcard $(CSRC)/*.h) include/rtamd.h
 # -ffp-contract=off: the intersector must round like the reference's scalar code (bit-exact triangle IDs)
 # -fno-slp-vectorize: the SLP vectorizer packs the triangle test into v_pk_* ops glued by ~35 v_movs; measured 4 % slower

@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 L2_PEAK_GBS = 34500.0   # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
-NODE_BYTES, TRI_BYTES = 64, 64   # the walk's quantised 4-wide node (round 1-2a: 128-B float nodes) and the triangle record
+NODE_BYTES, TRI_BYTES = 80, 64   # the walk's quantised 8-wide node (round 2: 64-B 4-wide nodes; round 1: 128-B float nodes) and the triangle record
 # k_extend per ray besides node/triangle fetches: ray origin + direction (32) + flags / throughput (16) + hit write (16) + queue read/write (8)
 # + the gate box of the reported hit (32)
 EXTEND_FIXED_BYTES = 104

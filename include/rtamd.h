@@ -86,14 +86,16 @@ typedef struct { uint32_t ID; float t, alpha, beta, gamma; } rt_hit;  /* Interse
 typedef struct {
     uint32_t n_tris, n_lights;
     uint32_t bvh2_nodes, bvh2_depth, bvh2_leaves, bvh2_max_leaf;   /* the reference-topology tree (Geometry.h:391) */
-    uint32_t wide_nodes, wide_max_stack;                           /* the flattened 4-wide tree the kernels walk */
+    uint32_t wide_nodes, wide_max_stack;                           /* the 8-wide tree the kernels walk: nodes (80 B each), and the most 8-byte stack entries a walk can have waiting */
     uint64_t device_bytes;
     float build_seconds;
+    uint32_t collapse_nodes;                                       /* the 4-wide collapse of the reference tree the builders produce (128 B per node): what the walk tree and the gate boxes are derived from */
+    uint32_t wide_levels;                                          /* levels of the 8-wide tree */
 } rt_scene_info;
 
 typedef struct {
     uint64_t closest_rays, any_rays;        /* rays issued (Scene::traverse / Scene::visible equivalents) */
-    uint64_t nodes_visited, tris_tested;    /* closest-hit walks: wide-node fetches (64 B each: the quantised nodes) and triangle-record fetches (64 B each) */
+    uint64_t nodes_visited, tris_tested;    /* closest-hit walks: wide-node fetches (80 B each: the 8-wide quantised nodes) and triangle-record fetches (64 B each) */
     uint64_t exact_path_rays;               /* rays routed through the reference-order fallback walk */
     uint64_t any_nodes_visited, any_tris_tested;  /* the same two counts for any-hit (Scene::visible) walks */
     uint64_t lane_slots, lane_busy;         /* closest-hit walks: 64 x wave traversal steps, and how many of those lanes held a ray */
@@ -126,13 +128,15 @@ int rt_scene_set_camera(rt_scene* scene, const rt_camera* cam);
 int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
 /* DFS leaf order of the reference tree (triangle indices), for structural parity checks. */
 int rt_scene_leaf_order(const rt_scene* scene, uint32_t* out_n_tris);
-/* The flattened 4-wide tree as the builders produce it (wide_nodes x 128 B: lox[4] loy[4] loz[4] hix[4] hiy[4] hiz[4] child[4] pad[4]) as it sits in
- * device memory, for structural checks (device-side build == host build). */
+/* The 4-wide collapse of the reference tree as the builders produce it (collapse_nodes x 128 B: lox[4] loy[4] loz[4] hix[4] hiy[4] hiz[4]
+ * child[4] pad[4]) as it sits in device memory, for structural checks (device-side build == host build). */
 int rt_scene_debug_wide_nodes(rt_scene* scene, void* out, size_t max_nodes);
-/* The same tree as the traversal kernels read it (wide_nodes x 64 B: org[3] scale[3] lox loy loz hix hiy hiz child[4]; child k's box
- * is org + byte k of the plane word x scale, lo rounded down, hi up) and the per-triangle gate boxes (n_tris x 32 B: lo[3] pad hi[3] pad,
- * in DFS leaf order: the reference box whose rayAABB (Geometry.h:207) decides whether upstream tests that triangle).  Either may be NULL. */
-int rt_scene_debug_walk_nodes(rt_scene* scene, void* nodes_out, size_t max_nodes, void* gate_out, size_t max_tris);
+/* What the traversal kernels read, derived on the device from the above: the 8-wide tree (wide_nodes x 80 B: org[3], int8 exponents
+ * ex ey ez + imask, child_base, tri_base, meta[8], plane bytes lox[8] loy[8] loz[8] hix[8] hiy[8] hiz[8]; slot s's box is
+ * org + byte s x 2^e, lo rounded down, hi up; csrc/rt_common.h DNode8), the per-triangle gate boxes (n_tris x 32 B: lo[3] pad hi[3] pad, in DFS
+ * leaf order: the reference box whose rayAABB (Geometry.h:207) decides whether upstream tests that triangle) and the triangle records in the
+ * order the 8-wide tree names them (n_tris x 64 B: v0 v1 v2 n d 1/area rank material).  Any pointer may be NULL. */
+int rt_scene_debug_walk_nodes(rt_scene* scene, void* nodes_out, size_t max_nodes, void* gate_out, size_t max_tris, void* trisw_out);
 /* Host-only structure query: runs the same builder without touching a device (leaf_order/info may be NULL).
  * Not a compute path: nothing can be traversed or rendered without a GPU. */
 int rt_host_build_info(const rt_scene_desc* desc, uint32_t* leaf_order, rt_scene_info* info);
@@ -143,7 +147,7 @@ int rt_host_build_info(const rt_scene_desc* desc, uint32_t* leaf_order, rt_scene
 int rt_matrix_invert(const float* m16, float* out16);
 
 /* --- IntersectionData Scene::traverse(const Ray&) (Scene.h:118), batched.
- * `mode`: 0 = 4-wide ordered walk (+ reference-order fallback for rays with a zero/denormal
+ * `mode`: 0 = 8-wide conservative walk + gate-box check (+ reference-order fallback for rays with a zero/denormal
  * direction component), 1 = reference-order walk for every ray (validation).
  * Host-buffer form copies in/out; the _dev form takes device pointers and a hipStream_t. */
 int rt_intersect_closest(rt_scene* scene, const rt_ray* rays, size_t n, rt_hit* out, int mode);
@@ -152,7 +156,7 @@ int rt_intersect_closest_dev(rt_scene* scene, const rt_ray* d_rays, size_t n, rt
  * graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same arguments and results, bit for bit; the
  * traversal scratch (work counter + stack overflow) comes from one static device array of ~42 MB per GPU instead of the
  * scene's own hipMalloc'ed arrays, and the call itself performs no hipMalloc / hipFree.  Limits: n <= 2^24 rays per call
- * (RT_ERR_INVALID beyond), and a scene whose stack bounds -- (wide_max_stack - 24) + the binary tree's bound -- exceed 80
+ * (RT_ERR_INVALID beyond), and a scene whose stack bounds -- 2 x (wide_max_stack - 12) + the binary tree's bound -- exceed 80
  * words per lane is refused with RT_ERR_UNSUPPORTED.  Every call on a GPU shares that GPU's array: calls that overlap
  * on one GPU (two streams, two host threads) race -- run them on one stream.  The scene's device must be current. */
 int rt_intersect_closest_noalloc(rt_scene* scene, const rt_ray* d_rays, size_t n, rt_hit* d_out, int mode, void* stream);

@@ -30,7 +30,7 @@ class RtError(RuntimeError):
 class SceneInfo(C.Structure):
     _fields_ = [("n_tris", C.c_uint32), ("n_lights", C.c_uint32), ("bvh2_nodes", C.c_uint32), ("bvh2_depth", C.c_uint32),
                 ("bvh2_leaves", C.c_uint32), ("bvh2_max_leaf", C.c_uint32), ("wide_nodes", C.c_uint32), ("wide_max_stack", C.c_uint32),
-                ("device_bytes", C.c_uint64), ("build_seconds", C.c_float)]
+                ("device_bytes", C.c_uint64), ("build_seconds", C.c_float), ("collapse_nodes", C.c_uint32), ("wide_levels", C.c_uint32)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -45,6 +45,12 @@ class Counters(C.Structure):
     def asdict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
+
+# DNode8 / DTri of csrc/rt_common.h as the walk reads them
+WALK_NODE_DTYPE = np.dtype([("org", np.float32, 3), ("exp", np.int8, 3), ("imask", np.uint8), ("child_base", np.uint32), ("tri_base", np.uint32),
+                            ("meta", np.uint8, 8), ("lo", np.uint8, (3, 8)), ("hi", np.uint8, (3, 8))])
+WALK_TRI_DTYPE = np.dtype([("v", np.float32, (3, 3)), ("n", np.float32, 3), ("d", np.float32), ("inv_area", np.float32), ("rank", np.uint32), ("mat_gsign", np.uint32)])
+assert WALK_NODE_DTYPE.itemsize == 80 and WALK_TRI_DTYPE.itemsize == 64
 
 _lib = None
 
@@ -91,7 +97,7 @@ def lib():
         _sig(L, "rt_scene_get_info", [vp, C.POINTER(SceneInfo)])
         _sig(L, "rt_scene_leaf_order", [vp, vp])
         _sig(L, "rt_scene_debug_wide_nodes", [vp, vp, sz])
-        _sig(L, "rt_scene_debug_walk_nodes", [vp, vp, sz, vp, sz])
+        _sig(L, "rt_scene_debug_walk_nodes", [vp, vp, sz, vp, sz, vp])
         _sig(L, "rt_host_build_info", [C.POINTER(SceneDesc), vp, C.POINTER(SceneInfo)])
         _sig(L, "rt_intersect_closest", [vp, vp, sz, vp, i32])
         _sig(L, "rt_intersect_closest_dev", [vp, vp, sz, vp, i32, vp])
@@ -195,19 +201,21 @@ class Scene:
         return o
 
     def wide_nodes(self):
-        """The 4-wide tree from device memory: structured array of 128-B nodes."""
-        n = self.info()["wide_nodes"]
+        """The 4-wide collapse of the reference tree from device memory: structured array of 128-B nodes."""
+        n = self.info()["collapse_nodes"]
         out = np.zeros(n, np.dtype([("box", np.float32, (6, 4)), ("child", np.uint32, 4), ("pad", np.uint32, 4)]))
         _check(self.L.rt_scene_debug_wide_nodes(self.h, out.ctypes.data, n), "rt_scene_debug_wide_nodes")
         return out
 
     def walk_nodes(self):
-        """(nodes, gate): the 64-B nodes the traversal kernels read and the per-triangle gate boxes (DFS leaf order)."""
+        """(nodes, gate, trisw): the 80-B 8-wide nodes the traversal kernels read (csrc/rt_common.h DNode8), the per-triangle gate
+        boxes (DFS leaf order) and the triangle records in the order the 8-wide tree names them (DFS rank in `rank`)."""
         n = self.info()["wide_nodes"]
-        nodes = np.zeros(n, np.dtype([("org", np.float32, 3), ("scale", np.float32, 3), ("lo", np.uint8, (3, 4)), ("hi", np.uint8, (3, 4)), ("child", np.uint32, 4)]))
+        nodes = np.zeros(n, WALK_NODE_DTYPE)
         gate = np.zeros(self.ntris, np.dtype([("lo", np.float32, 3), ("pad0", np.float32), ("hi", np.float32, 3), ("pad1", np.float32)]))
-        _check(self.L.rt_scene_debug_walk_nodes(self.h, nodes.ctypes.data, n, gate.ctypes.data, self.ntris), "rt_scene_debug_walk_nodes")
-        return nodes, gate
+        trisw = np.zeros(self.ntris, WALK_TRI_DTYPE)
+        _check(self.L.rt_scene_debug_walk_nodes(self.h, nodes.ctypes.data, n, gate.ctypes.data, self.ntris, trisw.ctypes.data), "rt_scene_debug_walk_nodes")
+        return nodes, gate, trisw
 
     # Scene::traverse (Scene.h:118)
     def traverse(self, rays, mode=0):

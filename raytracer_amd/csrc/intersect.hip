@@ -90,10 +90,10 @@ struct AnyJob {
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_intersect_closest(DScene S, const float* __restrict__ rays, uint32_t n,
                                                                 rt_hit* __restrict__ out, int mode, unsigned long long* work,
-                                                                uint32_t* spill4, uint32_t* spill2, DCounters* counters) {
-    __shared__ uint32_t lds_stack[RT_STACK_WORDS];
+                                                                uint32_t* spillw, uint32_t* spill2, DCounters* counters) {
+    __shared__ __align__(16) uint32_t lds_stack[RT_STACK_WORDS];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
-    RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
+    RT_TRAV_STACK_INIT(st, lds_stack, spillw, gtid, gstride)
     uint32_t cn = 0, ct = 0, cx = 0;
     ClosestJob job{S, rays, out, 0u};
     CounterSource src; src.init(work, n);
@@ -107,10 +107,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_intersect_closest(D
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_intersect_any(DScene S, const float* __restrict__ segs, uint32_t n,
                                                             uint8_t* __restrict__ out, int mode, unsigned long long* work,
-                                                            uint32_t* spill4, uint32_t* spill2, DCounters* counters) {
-    __shared__ uint32_t lds_stack[RT_STACK_WORDS];
+                                                            uint32_t* spillw, uint32_t* spill2, DCounters* counters) {
+    __shared__ __align__(16) uint32_t lds_stack[RT_STACK_WORDS];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
-    RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
+    RT_TRAV_STACK_INIT(st, lds_stack, spillw, gtid, gstride)
     uint32_t cn = 0, ct = 0, cx = 0;
     AnyJob job{segs, out, 0u};
     CounterSource src; src.init(work, n);
@@ -142,86 +142,6 @@ __global__ void k_generate_rays(DScene S, const float* __restrict__ xy, size_t n
     f3 dir = dcam - org;
     float* r = out + i * 6;
     r[0] = org.x; r[1] = org.y; r[2] = org.z; r[3] = dir.x; r[4] = dir.y; r[5] = dir.z;
-}
-
-// ------------------------------------------------------------------------------------------------ the walk's view of the tree
-// nodes4 (the builders' output, float boxes) -> nodesq (64 B per node, child boxes on a 256-step grid of the node's own box,
-// rounded outwards) + gate (per triangle, the float box of its leaf slot: what rt_settle tests with upstream's expression).
-// One thread per node.  The grid arithmetic is done in double: a plane that lands a rounding error (2^-52 of the node's
-// extent) inside the box it should contain is covered many times over by the walk's slack (2^-17 of the scene's extent).
-__global__ void k_quantise(const DNode4* __restrict__ in, uint32_t n, const DTri* __restrict__ tris, DNodeQ* __restrict__ out, DGate* __restrict__ gate) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const DNode4 nd = in[i];
-    // What the walk culls with.  Inner child: the reference node's box.  Leaf slot: the bounds of its triangles' vertices --
-    // what a hit needs is that the slot's box holds the triangle; the slot's reference box (the gate, below) can be far
-    // larger: a single-triangle leaf carries its parent's box, a one-triangle scene a box of +-FLT_MAX.
-    float lo[3][4], hi[3][4];
-    for (int k = 0; k < 4; k++) {
-        const uint32_t ref = nd.child[k];
-        lo[0][k] = nd.lox[k]; lo[1][k] = nd.loy[k]; lo[2][k] = nd.loz[k]; hi[0][k] = nd.hix[k]; hi[1][k] = nd.hiy[k]; hi[2][k] = nd.hiz[k];
-#ifndef RT_EXP_LOOSE_LEAVES   // (experiment switch: leaf slots keep their reference box, to tell the tight boxes' share of the gain from the nodes')
-        if (ref != RT_REF_EMPTY && (ref & RT_REF_LEAF)) {
-#else
-        if (false) {
-#endif
-            const uint32_t first = ref & RT_LEAF_FIRST_MASK, cnt = ((ref >> 27) & 15u) + 1u;
-            for (int a = 0; a < 3; a++) { lo[a][k] = RT_INF; hi[a][k] = -RT_INF; }
-            for (uint32_t t = 0; t < cnt; t++) {
-                const DTri& tr = tris[first + t];
-                for (int a = 0; a < 3; a++) {
-                    lo[a][k] = fminf(lo[a][k], fminf(tr.v0[a], fminf(tr.v1[a], tr.v2[a])));
-                    hi[a][k] = fmaxf(hi[a][k], fmaxf(tr.v0[a], fmaxf(tr.v1[a], tr.v2[a])));
-                }
-            }
-        }
-    }
-    DNodeQ q;
-    float scale[3];
-    uint32_t wlo[3], whi[3];
-    for (int a = 0; a < 3; a++) {
-        float org = RT_INF, top = -RT_INF;
-        for (int k = 0; k < 4; k++)
-            if (nd.child[k] != RT_REF_EMPTY) { org = fminf(org, lo[a][k]); top = fmaxf(top, hi[a][k]); }
-        if (!(org <= top)) { org = 0.0f; top = 0.0f; }   // a node without children (the root of an empty scene is never read)
-        const double ext = (double)top - (double)org;
-        double s = 0.0;
-        if (ext > 0.0) {
-            int e; (void)frexp(ext / 255.0, &e);          // ext / 255 = m * 2^e, m in [0.5, 1)
-            if (e < -126) e = -126;                         // keep the step a normal float
-            s = ldexp(1.0, e);
-        }
-        for (;;) {
-            bool fits = true;
-            uint32_t l = 0, h = 0;
-            for (int k = 0; k < 4; k++) {
-                uint32_t ql = 255u, qh = 0u;                // unused slot: an inverted box (the walk also tests the child word)
-                if (nd.child[k] != RT_REF_EMPTY && s > 0.0) {
-                    const double fl = floor(((double)lo[a][k] - (double)org) / s), ce = ceil(((double)hi[a][k] - (double)org) / s);
-                    if (ce > 255.0) { fits = false; break; }
-                    ql = fl < 0.0 ? 0u : (uint32_t)fl; qh = (uint32_t)ce;
-                } else if (nd.child[k] != RT_REF_EMPTY) { ql = 0u; qh = 0u; }
-                l |= ql << (8 * k); h |= qh << (8 * k);
-            }
-            if (fits) { wlo[a] = l; whi[a] = h; break; }
-            s *= 2.0;
-        }
-        q.org[a] = org; scale[a] = (float)s;
-    }
-    q.scale_x = scale[0]; q.scale_y = scale[1]; q.scale_z = scale[2];
-    q.lox = wlo[0]; q.loy = wlo[1]; q.loz = wlo[2]; q.hix = whi[0]; q.hiy = whi[1]; q.hiz = whi[2];
-    for (int k = 0; k < 4; k++) {
-        const uint32_t ref = nd.child[k];
-        q.child[k] = ref;
-        if (ref != RT_REF_EMPTY && (ref & RT_REF_LEAF)) {
-            const uint32_t first = ref & RT_LEAF_FIRST_MASK, cnt = ((ref >> 27) & 15u) + 1u;
-            DGate g;
-            g.lo[0] = nd.lox[k]; g.lo[1] = nd.loy[k]; g.lo[2] = nd.loz[k]; g.pad0 = 0.0f;
-            g.hi[0] = nd.hix[k]; g.hi[1] = nd.hiy[k]; g.hi[2] = nd.hiz[k]; g.pad1 = 0.0f;
-            for (uint32_t t = 0; t < cnt; t++) gate[first + t] = g;
-        }
-    }
-    out[i] = q;
 }
 
 // ------------------------------------------------------------------------------------------------ scene
@@ -279,22 +199,11 @@ extern "C" int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_
     if (!h.env_cond.empty() && ((rc = upload(s, h.env_cond, &d.env_cond)) || (rc = upload(s, h.env_marg, &d.env_marg)))) return fail(rc);
     d.n_tris = h.n_tris; d.n_lights = (uint32_t)h.lights.size();
     d.n_nodes4 = h.n_nodes4; d.n_nodes2 = h.n_nodes2;
-    {   // the walk's own arrays, derived on the device from whichever builder made nodes4
-        void* pq = nullptr; void* pg = nullptr;
-        const size_t bq = sizeof(DNodeQ) * std::max<size_t>(h.n_nodes4, 1), bg = sizeof(DGate) * std::max<size_t>(h.n_tris, 1);
-        if (hipMalloc(&pq, bq) != hipSuccess) { rt_set_error("rt_scene_create: out of device memory (walk nodes)"); return fail(RT_ERR_NOMEM); }
-        s->allocs.push_back(pq);
-        if (hipMalloc(&pg, bg) != hipSuccess) { rt_set_error("rt_scene_create: out of device memory (gate boxes)"); return fail(RT_ERR_NOMEM); }
-        s->allocs.push_back(pg);
-        s->device_bytes += bq + bg;
-        d.nodesq = (const DNodeQ*)pq; d.gate = (const DGate*)pg;
-        if (h.n_nodes4) {
-            hipLaunchKernelGGL(k_quantise, dim3((h.n_nodes4 + 255u) / 256u), dim3(256), 0, 0, d.nodes4, h.n_nodes4, d.tris, (DNodeQ*)pq, (DGate*)pg);
-            if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { rt_set_error("rt_scene_create: k_quantise failed"); return fail(RT_ERR_DEVICE); }
-        }
-    }
+    // the walk's own arrays (gate boxes, 8-wide nodes, walk-ordered triangle records), derived on the device from whichever
+    // builder made nodes4 (walk_tree.hip)
+    if ((rc = rt_build_walk_tree(s))) return fail(rc);
     d.root_ref = d.n_tris ? 0u : RT_REF_EMPTY;
-    d.max_stack4 = h.max_stack4; d.max_stack2 = h.max_stack2;
+    d.max_stack2 = h.max_stack2;   // d.walk_stack: set by rt_build_walk_tree
     d.abs_max = h.abs_max;
     memcpy(d.bg_colour, h.bg_colour, 12); d.bg_kind = h.bg_kind; d.bg_tex = h.bg_tex;
     memcpy(d.scene_centre, h.centre, 12); d.scene_radius = h.radius;
@@ -308,10 +217,10 @@ extern "C" int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_
     s->persistent_blocks = prop.multiProcessorCount * per_cu;
     size_t threads = (size_t)s->persistent_blocks * RT_BLOCK;
     void* p = nullptr;
-    if (h.max_stack4 > RT_STACK_LDS) {
-        size_t bytes = threads * (h.max_stack4 - RT_STACK_LDS) * sizeof(uint32_t) * (RT_STACK_KEYS ? 2 : 1);
+    if (RT_SPILL_WORDS(h.walk_stack)) {
+        size_t bytes = threads * RT_SPILL_WORDS(h.walk_stack) * sizeof(uint32_t);
         if (hipMalloc(&p, bytes) != hipSuccess) { rt_set_error("rt_scene_create: out of device memory (stack spill)"); return fail(RT_ERR_NOMEM); }
-        s->allocs.push_back(p); s->device_bytes += bytes; s->d_spill4 = (uint32_t*)p;
+        s->allocs.push_back(p); s->device_bytes += bytes; s->d_spillw = (uint32_t*)p;
     }
     {
         size_t bytes = threads * std::max<uint32_t>(h.max_stack2, 2) * sizeof(uint32_t);
@@ -349,7 +258,7 @@ extern "C" int rt_scene_get_info(const rt_scene* s, rt_scene_info* o) {
     const HostScene& h = s->host;
     o->n_tris = h.n_tris; o->n_lights = (uint32_t)h.lights.size();
     o->bvh2_nodes = h.n_nodes2; o->bvh2_depth = h.depth2; o->bvh2_leaves = h.leaves2; o->bvh2_max_leaf = h.max_leaf2;
-    o->wide_nodes = h.n_nodes4; o->wide_max_stack = h.max_stack4;
+    o->wide_nodes = h.n_nodes8; o->wide_max_stack = h.walk_stack; o->collapse_nodes = h.n_nodes4; o->wide_levels = h.walk_levels;
     o->device_bytes = s->device_bytes; o->build_seconds = (float)h.build_seconds;
     return RT_OK;
 }
@@ -362,12 +271,14 @@ extern "C" int rt_scene_debug_wide_nodes(rt_scene* s, void* out, size_t max_node
     if (s->host.n_nodes4) RT_HIP(hipMemcpy(out, s->d.nodes4, (size_t)s->host.n_nodes4 * sizeof(DNode4), hipMemcpyDeviceToHost));
     return RT_OK;
 }
-// The same tree as the walk reads it (64 B per node) and the per-triangle gate boxes (32 B each); either pointer may be NULL.
-extern "C" int rt_scene_debug_walk_nodes(rt_scene* s, void* nodes_out, size_t max_nodes, void* gate_out, size_t max_tris) {
+// The tree the walk reads (80 B per 8-wide node), the per-triangle gate boxes (32 B each, DFS rank order) and the walk-ordered
+// triangle records (64 B each); any pointer may be NULL.
+extern "C" int rt_scene_debug_walk_nodes(rt_scene* s, void* nodes_out, size_t max_nodes, void* gate_out, size_t max_tris, void* trisw_out) {
     if (!s) { rt_set_error("rt_scene_debug_walk_nodes: NULL scene"); return RT_ERR_INVALID; }
-    if ((nodes_out && max_nodes < s->host.n_nodes4) || (gate_out && max_tris < s->host.n_tris)) { rt_set_error("rt_scene_debug_walk_nodes: buffer too small"); return RT_ERR_INVALID; }
-    if (nodes_out && s->host.n_nodes4) RT_HIP(hipMemcpy(nodes_out, s->d.nodesq, (size_t)s->host.n_nodes4 * sizeof(DNodeQ), hipMemcpyDeviceToHost));
+    if ((nodes_out && max_nodes < s->host.n_nodes8) || ((gate_out || trisw_out) && max_tris < s->host.n_tris)) { rt_set_error("rt_scene_debug_walk_nodes: buffer too small"); return RT_ERR_INVALID; }
+    if (nodes_out && s->host.n_nodes8) RT_HIP(hipMemcpy(nodes_out, s->d.nodes8, (size_t)s->host.n_nodes8 * sizeof(DNode8), hipMemcpyDeviceToHost));
     if (gate_out && s->host.n_tris) RT_HIP(hipMemcpy(gate_out, s->d.gate, (size_t)s->host.n_tris * sizeof(DGate), hipMemcpyDeviceToHost));
+    if (trisw_out && s->host.n_tris) RT_HIP(hipMemcpy(trisw_out, s->d.trisw, (size_t)s->host.n_tris * sizeof(DTri), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 extern "C" int rt_scene_leaf_order(const rt_scene* s, uint32_t* out) {
@@ -386,7 +297,7 @@ extern "C" int rt_host_build_info(const rt_scene_desc* desc, uint32_t* leaf_orde
         memset(info, 0, sizeof(*info));
         info->n_tris = h.n_tris; info->n_lights = (uint32_t)h.lights.size();
         info->bvh2_nodes = h.n_nodes2; info->bvh2_depth = h.depth2; info->bvh2_leaves = h.leaves2; info->bvh2_max_leaf = h.max_leaf2;
-        info->wide_nodes = h.n_nodes4; info->wide_max_stack = h.max_stack4; info->build_seconds = (float)h.build_seconds;
+        info->wide_nodes = 0; info->wide_max_stack = 0; info->collapse_nodes = h.n_nodes4; info->wide_levels = 0; info->build_seconds = (float)h.build_seconds;
     }
     return RT_OK;
 }
@@ -447,10 +358,10 @@ extern "C" int rt_intersect_closest_dev(rt_scene* s, const rt_ray* d_rays, size_
         int blocks = (int)std::min<size_t>(((size_t)m + RT_BLOCK - 1) / RT_BLOCK, (size_t)s->persistent_blocks);
         if (s->count_enabled)
             hipLaunchKernelGGL(k_intersect_closest<true>, dim3(blocks), dim3(RT_BLOCK), 0, st, s->d, in, m, d_out + off, mode, s->d_work,
-                               s->d_spill4, s->d_spill2, s->d_counters);
+                               s->d_spillw, s->d_spill2, s->d_counters);
         else
             hipLaunchKernelGGL(k_intersect_closest<false>, dim3(blocks), dim3(RT_BLOCK), 0, st, s->d, in, m, d_out + off, mode, s->d_work,
-                               s->d_spill4, s->d_spill2, s->d_counters);
+                               s->d_spillw, s->d_spill2, s->d_counters);
         RT_HIP(hipGetLastError());
     }
     return scratch_release(s, st);
@@ -470,10 +381,10 @@ extern "C" int rt_intersect_any_dev(rt_scene* s, const rt_segment* d_segs, size_
         int blocks = (int)std::min<size_t>(((size_t)m + RT_BLOCK - 1) / RT_BLOCK, (size_t)s->persistent_blocks);
         if (s->count_enabled)
             hipLaunchKernelGGL(k_intersect_any<true>, dim3(blocks), dim3(RT_BLOCK), 0, st, s->d, in, m, d_out + off, mode, s->d_work,
-                               s->d_spill4, s->d_spill2, s->d_counters);
+                               s->d_spillw, s->d_spill2, s->d_counters);
         else
             hipLaunchKernelGGL(k_intersect_any<false>, dim3(blocks), dim3(RT_BLOCK), 0, st, s->d, in, m, d_out + off, mode, s->d_work,
-                               s->d_spill4, s->d_spill2, s->d_counters);
+                               s->d_spillw, s->d_spill2, s->d_counters);
         RT_HIP(hipGetLastError());
     }
     return scratch_release(s, st);
@@ -515,7 +426,7 @@ extern "C" int rt_intersect_closest_noalloc(rt_scene* s, const rt_ray* d_rays, s
     if (!s || (n && (!d_rays || !d_out))) { rt_set_error("rt_intersect_closest_noalloc: NULL argument"); return RT_ERR_INVALID; }
     if (check_mode(mode)) return RT_ERR_INVALID;
     if (n > RT_NA_MAX_RAYS) { rt_set_error("rt_intersect_closest_noalloc: at most 2^24 rays per call (use rt_intersect_closest_dev for larger batches)"); return RT_ERR_INVALID; }
-    const uint32_t s4 = s->host.max_stack4 > RT_STACK_LDS ? (s->host.max_stack4 - RT_STACK_LDS) * (RT_STACK_KEYS ? 2u : 1u) : 0u;
+    const uint32_t s4 = RT_SPILL_WORDS(s->host.walk_stack);
     const uint32_t s2 = std::max<uint32_t>(s->host.max_stack2, 2);
     if (s4 + s2 > RT_NA_WORDS) {
         rt_set_error("rt_intersect_closest_noalloc: the scene's traversal stack bounds (" + std::to_string(s4) + " + " + std::to_string(s2) +
@@ -530,10 +441,10 @@ extern "C" int rt_intersect_closest_noalloc(rt_scene* s, const rt_ray* d_rays, s
     RT_HIP(hipMemsetAsync(ptr, 0, sizeof(unsigned long long), st));
     const uint32_t m = (uint32_t)n;
     const unsigned blocks = (unsigned)std::min<size_t>(((size_t)m + RT_BLOCK - 1) / RT_BLOCK, std::min<size_t>(RT_NA_BLOCKS, (size_t)s->persistent_blocks));
-    uint32_t* spill4 = s4 ? ptr + RT_NA_HEADER : nullptr;
+    uint32_t* spillw = s4 ? ptr + RT_NA_HEADER : nullptr;
     uint32_t* spill2 = ptr + RT_NA_HEADER + (size_t)RT_NA_THREADS * s4;
     hipLaunchKernelGGL(k_intersect_closest<false>, dim3(blocks), dim3(RT_BLOCK), 0, st, s->d, (const float*)d_rays, m, d_out, mode,
-                       (unsigned long long*)ptr, spill4, spill2, s->d_counters);
+                       (unsigned long long*)ptr, spillw, spill2, s->d_counters);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }

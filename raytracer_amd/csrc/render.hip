@@ -293,11 +293,11 @@ struct ExtendJob {
 // TAG only gives the launches of a one-stream renderer (rt_renderer_set_streams) a kernel name of their own, so that a
 // profiler's per-kernel average keeps the shared (two-stream) and the unshared launch durations apart.
 template <bool LT, bool COUNT, int TAG = 0>
-__global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_extend(DScene S, RBuf R, Ctl* ctl, int cur, int first, uint32_t* spill4, uint32_t* spill2,
+__global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_extend(DScene S, RBuf R, Ctl* ctl, int cur, int first, uint32_t* spillw, uint32_t* spill2,
                                                      DCounters* counters) {
-    __shared__ uint32_t lds_stack[RT_STACK_WORDS];
+    __shared__ __align__(16) uint32_t lds_stack[RT_STACK_WORDS];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
-    RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
+    RT_TRAV_STACK_INIT(st, lds_stack, spillw, gtid, gstride)
     const uint32_t n = ctl->n_active[cur];
     uint32_t cn = 0, ct = 0, cx = 0;
     ExtendJob<LT> job{S, R, R.q_active[cur], first};
@@ -532,10 +532,10 @@ struct ConnectJob {
     }
 };
 template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_connect(DScene S, RBuf R, Ctl* ctl, uint32_t* spill4, uint32_t* spill2, DCounters* counters) {
-    __shared__ uint32_t lds_stack[RT_STACK_WORDS];
+__global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_connect(DScene S, RBuf R, Ctl* ctl, uint32_t* spillw, uint32_t* spill2, DCounters* counters) {
+    __shared__ __align__(16) uint32_t lds_stack[RT_STACK_WORDS];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
-    RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
+    RT_TRAV_STACK_INIT(st, lds_stack, spillw, gtid, gstride)
     const uint32_t n = ctl->n_shadow;
     uint32_t cn = 0, ct = 0, cx = 0;
     ConnectJob job{R, ctl->nf_shadow != 0};
@@ -653,10 +653,10 @@ struct CameraJob {
     }
 };
 template <bool FILTERED>
-__global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_connect_camera(DScene S, RBuf R, Ctl* ctl, float* film, DFilter F, uint32_t* spill4, uint32_t* spill2, DCounters* counters) {
-    __shared__ uint32_t lds_stack[RT_STACK_WORDS];
+__global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_connect_camera(DScene S, RBuf R, Ctl* ctl, float* film, DFilter F, uint32_t* spillw, uint32_t* spill2, DCounters* counters) {
+    __shared__ __align__(16) uint32_t lds_stack[RT_STACK_WORDS];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
-    RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
+    RT_TRAV_STACK_INIT(st, lds_stack, spillw, gtid, gstride)
     const uint32_t n = ctl->n_shadow;
     uint32_t cn = 0, ct = 0, cx = 0;
     CameraJob<FILTERED> job{S, R, film, F};
@@ -811,10 +811,10 @@ __global__ __launch_bounds__(64) void k_mlt_chain(DScene S, RBuf R, float* film,
 // ------------------------------------------------------------------------------------------------ AOV / direct
 // albedo(), viewNormals(), direct() (Renderer.h:257-296): one ray through the pixel centre (Renderer.h:590).
 __global__ __launch_bounds__(RT_BLOCK) void k_aov(DScene S, RBuf R, Ctl* ctl, int mode, uint64_t seed, uint64_t first_sample, uint32_t n,
-                                                  uint32_t* spill4, uint32_t* spill2) {
-    __shared__ uint32_t lds_stack[RT_STACK_WORDS];
+                                                  uint32_t* spillw, uint32_t* spill2) {
+    __shared__ __align__(16) uint32_t lds_stack[RT_STACK_WORDS];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
-    RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
+    RT_TRAV_STACK_INIT(st, lds_stack, spillw, gtid, gstride)
     uint32_t cn = 0, ct = 0, cx = 0;
     for (;;) {
         unsigned long long base = fetch_chunk(&ctl->work[0][0]);
@@ -1144,10 +1144,10 @@ struct GatherJob {
     }
 };
 // VPL slots [v0, v0 + nv) against every gather request of the bounce
-__global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_gather(DScene S, RBuf R, Ctl* ctl, uint32_t v0, uint32_t nv, uint32_t* spill4, uint32_t* spill2, DCounters* counters) {
-    __shared__ uint32_t lds_stack[RT_STACK_WORDS];
+__global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_gather(DScene S, RBuf R, Ctl* ctl, uint32_t v0, uint32_t nv, uint32_t* spillw, uint32_t* spill2, DCounters* counters) {
+    __shared__ __align__(16) uint32_t lds_stack[RT_STACK_WORDS];
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x, gstride = gridDim.x * RT_BLOCK;
-    RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, S.max_stack4)
+    RT_TRAV_STACK_INIT(st, lds_stack, spillw, gtid, gstride)
     const uint32_t n = ctl->n_gather;
     if (n == 0) return;
     const uint32_t items = n * nv;   // the host keeps paths * nv below 2^31
@@ -1216,7 +1216,7 @@ struct rt_renderer {
     // rt_render requests not yet enqueued (see rt_render): consecutive sample ranges of one mode and seed
     struct Pending { bool active = false; int mode = 0, spp = 0; uint64_t seed = 0, first = 0; } pend;
     uint32_t batch_max = 1;
-    uint32_t* spill4 = nullptr;
+    uint32_t* spillw = nullptr;
     uint32_t* spill2 = nullptr;
     int trav_blocks = 0, flat_blocks = 0;
     int n_vpl = 0;
@@ -1226,7 +1226,7 @@ struct rt_renderer {
     // between the two lanes, so the tail of one batch's persistent kernels (a launch lasts as long as its slowest ray:
     // 0.6-2 ms of nearly idle GPU per k_extend launch on the bench scene) overlaps the other batch's work.  The active
     // lane's state lives in the fields above; use_lane() swaps.
-    struct Lane { hipStream_t stream = nullptr; RBuf R{}; Ctl* ctl = nullptr; uint32_t* spill4 = nullptr; uint32_t* spill2 = nullptr; };
+    struct Lane { hipStream_t stream = nullptr; RBuf R{}; Ctl* ctl = nullptr; uint32_t* spillw = nullptr; uint32_t* spill2 = nullptr; };
     Lane other;
     bool other_ready = false;
     int active_lane = 0;
@@ -1248,7 +1248,7 @@ static void prof_collect(rt_renderer* r);
 static void use_lane(rt_renderer* r, int lane) {
     if (r->active_lane == lane) return;
     std::swap(r->stream, r->other.stream); std::swap(r->R, r->other.R); std::swap(r->ctl, r->other.ctl);
-    std::swap(r->spill4, r->other.spill4); std::swap(r->spill2, r->other.spill2);
+    std::swap(r->spillw, r->other.spillw); std::swap(r->spill2, r->other.spill2);
     r->active_lane = lane;
 }
 static hipError_t sync_all(rt_renderer* r) {
@@ -1311,7 +1311,7 @@ static int ensure_other_lane(rt_renderer* r) {
     if ((rc = alloc_state(r, o.R, &o.ctl))) return rc;
     size_t threads = (size_t)r->trav_blocks * RT_BLOCK;
     const HostScene& h = r->scene->host;
-    if (h.max_stack4 > RT_STACK_LDS && (rc = dev_alloc(r, &o.spill4, threads * (h.max_stack4 - RT_STACK_LDS) * (RT_STACK_KEYS ? 2 : 1)))) return rc;
+    if (RT_SPILL_WORDS(h.walk_stack) && (rc = dev_alloc(r, &o.spillw, threads * RT_SPILL_WORDS(h.walk_stack)))) return rc;
     if ((rc = dev_alloc(r, &o.spill2, threads * std::max<uint32_t>(h.max_stack2, 2)))) return rc;
     RT_HIP(hipMemsetAsync(o.ctl, 0, sizeof(Ctl), o.stream));
     r->other_ready = true;
@@ -1404,7 +1404,7 @@ extern "C" int rt_renderer_create(rt_scene* scene, rt_renderer** out) {
     if (hipGetDeviceProperties(&prop, scene->device) != hipSuccess) return fail(RT_ERR_DEVICE);
     r->flat_blocks = prop.multiProcessorCount * 8;
     size_t threads = (size_t)r->trav_blocks * RT_BLOCK;
-    if (scene->host.max_stack4 > RT_STACK_LDS && (rc = dev_alloc(r, &r->spill4, threads * (scene->host.max_stack4 - RT_STACK_LDS) * (RT_STACK_KEYS ? 2 : 1)))) return fail(rc);
+    if (RT_SPILL_WORDS(scene->host.walk_stack) && (rc = dev_alloc(r, &r->spillw, threads * RT_SPILL_WORDS(scene->host.walk_stack)))) return fail(rc);
     if ((rc = dev_alloc(r, &r->spill2, threads * std::max<uint32_t>(scene->host.max_stack2, 2)))) return fail(rc);
     if (hipMemsetAsync(r->ctl, 0, sizeof(Ctl), r->stream) != hipSuccess || hipMemsetAsync(r->counters, 0, sizeof(DCounters), r->stream) != hipSuccess ||
         hipMemsetAsync(r->film_own, 0, sizeof(float) * (size_t)r->W * r->H * 3, r->stream) != hipSuccess)
@@ -1455,21 +1455,21 @@ static int render_path_like(rt_renderer* r, int mode, uint32_t batch, uint64_t s
     for (int b = 0; b < bounces; b++) {
         int cur = b & 1;
         LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n, live);
-        if (r->count_enabled) LAUNCHK(RT_KID_EXTEND, (k_extend<false, true>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
-        else if (r->lanes == 1) LAUNCHK(RT_KID_EXTEND, (k_extend<false, false, 1>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
-        else LAUNCHK(RT_KID_EXTEND, (k_extend<false, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
+        if (r->count_enabled) LAUNCHK(RT_KID_EXTEND, (k_extend<false, true>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spillw, r->spill2, r->counters);
+        else if (r->lanes == 1) LAUNCHK(RT_KID_EXTEND, (k_extend<false, false, 1>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spillw, r->spill2, r->counters);
+        else LAUNCHK(RT_KID_EXTEND, (k_extend<false, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spillw, r->spill2, r->counters);
         LAUNCH(k_bin, r->flat_blocks / 2, RT_BIN_BLOCK, R, r->ctl, cur, b == 0 ? 1 : 0);
         if (radiosity && S.env_cond) LAUNCHK(RT_KID_SHADE, (k_shade<true, true>), r->flat_blocks * 256 / RT_SHADE_BLOCK, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
         else if (radiosity) LAUNCHK(RT_KID_SHADE, (k_shade<true, false>), r->flat_blocks * 256 / RT_SHADE_BLOCK, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
         else if (S.env_cond) LAUNCHK(RT_KID_SHADE, (k_shade<false, true>), r->flat_blocks * 256 / RT_SHADE_BLOCK, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
         else LAUNCHK(RT_KID_SHADE, (k_shade<false, false>), r->flat_blocks * 256 / RT_SHADE_BLOCK, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
-        if (r->count_enabled) LAUNCHK(RT_KID_CONNECT, k_connect<true>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
-        else LAUNCHK(RT_KID_CONNECT, k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
+        if (r->count_enabled) LAUNCHK(RT_KID_CONNECT, k_connect<true>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spillw, r->spill2, r->counters);
+        else LAUNCHK(RT_KID_CONNECT, k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spillw, r->spill2, r->counters);
         if (radiosity) {
             const uint32_t per = std::max<uint32_t>(1u, (1u << 31) / std::max<uint32_t>(n, 1u));   // item indices are 32-bit: requests (<= n paths) x VPLs per launch < 2^31
             for (uint32_t v0 = 0; v0 < R.vpl_slots; v0 += per) {
                 if (v0) RT_HIP(hipMemsetAsync(&r->ctl->work_x[2], 0, sizeof(r->ctl->work_x[2]), r->stream));
-                LAUNCHK(RT_KID_GATHER, k_gather, r->trav_blocks, RT_BLOCK, S, R, r->ctl, v0, std::min<uint32_t>(per, R.vpl_slots - v0), r->spill4, r->spill2, r->counters);
+                LAUNCHK(RT_KID_GATHER, k_gather, r->trav_blocks, RT_BLOCK, S, R, r->ctl, v0, std::min<uint32_t>(per, R.vpl_slots - v0), r->spillw, r->spill2, r->counters);
             }
         }
     }
@@ -1488,8 +1488,8 @@ static int render_aov(rt_renderer* r, int mode, uint32_t batch, uint64_t seed, u
     RBuf& R = r->R;
     const uint32_t n = R.np_pad * batch;
     LAUNCH(k_ctl_reset, 1, 1, r->ctl, 0, 1, n, (uint32_t)r->W * r->H * batch);
-    LAUNCHK(RT_KID_EXTEND, k_aov, r->trav_blocks, RT_BLOCK, S, R, r->ctl, mode, seed, first_sample, n, r->spill4, r->spill2);
-    LAUNCHK(RT_KID_CONNECT, k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
+    LAUNCHK(RT_KID_EXTEND, k_aov, r->trav_blocks, RT_BLOCK, S, R, r->ctl, mode, seed, first_sample, n, r->spillw, r->spill2);
+    LAUNCHK(RT_KID_CONNECT, k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spillw, r->spill2, r->counters);
     LAUNCH(k_ctl_final, 1, 1, r->ctl);
     LAUNCHK(RT_KID_ACCUMULATE, k_accumulate, r->flat_blocks, 256, R, r->film, batch);
     RT_HIP(hipGetLastError());
@@ -1503,16 +1503,16 @@ static int render_light(rt_renderer* r, uint32_t batch, uint64_t seed, uint64_t 
     const uint32_t n = npix * batch;  // W*H light paths per spp (Renderer.h:331-337)
     LAUNCH(k_ctl_reset, 1, 1, r->ctl, 0, 1, 0u, 0u);
     LAUNCHK(RT_KID_GENERATE, k_lt_generate, r->flat_blocks / 2, RT_LT_BLOCK, S, R, r->ctl, n, npix, seed, first_sample);
-    if (r->filter.kind) LAUNCHK(RT_KID_CONNECT, k_connect_camera<true>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->filter, r->spill4, r->spill2, r->counters);
-    else LAUNCHK(RT_KID_CONNECT, k_connect_camera<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->filter, r->spill4, r->spill2, r->counters);
+    if (r->filter.kind) LAUNCHK(RT_KID_CONNECT, k_connect_camera<true>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->filter, r->spillw, r->spill2, r->counters);
+    else LAUNCHK(RT_KID_CONNECT, k_connect_camera<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->filter, r->spillw, r->spill2, r->counters);
     for (int b = 0; b < RT_MAX_DEPTH + 2; b++) {
         int cur = b & 1;
         LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n, n);
-        LAUNCHK(RT_KID_EXTEND, (k_extend<true, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
+        LAUNCHK(RT_KID_EXTEND, (k_extend<true, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spillw, r->spill2, r->counters);
         LAUNCH(k_bin, r->flat_blocks / 2, RT_BIN_BLOCK, R, r->ctl, cur, b == 0 ? 1 : 0);
         LAUNCHK(RT_KID_SHADE, k_lt_shade, r->flat_blocks / 2, RT_LT_BLOCK, S, R, r->ctl, cur);
-        if (r->filter.kind) LAUNCHK(RT_KID_CONNECT, k_connect_camera<true>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->filter, r->spill4, r->spill2, r->counters);
-        else LAUNCHK(RT_KID_CONNECT, k_connect_camera<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->filter, r->spill4, r->spill2, r->counters);
+        if (r->filter.kind) LAUNCHK(RT_KID_CONNECT, k_connect_camera<true>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->filter, r->spillw, r->spill2, r->counters);
+        else LAUNCHK(RT_KID_CONNECT, k_connect_camera<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->film, r->filter, r->spillw, r->spill2, r->counters);
     }
     LAUNCH(k_ctl_final, 1, 1, r->ctl);
     RT_HIP(hipGetLastError());
@@ -1527,11 +1527,11 @@ static int render_mlt(rt_renderer* r, uint32_t chains, uint64_t seed, uint64_t f
     for (int b = 0; b < RT_MAX_DEPTH + 2; b++) {
         int cur = b & 1;
         LAUNCH(k_ctl_reset, 1, 1, r->ctl, cur, b == 0 ? 1 : 0, n, n);
-        LAUNCHK(RT_KID_EXTEND, (k_extend<false, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spill4, r->spill2, r->counters);
+        LAUNCHK(RT_KID_EXTEND, (k_extend<false, false>), r->trav_blocks, RT_BLOCK, S, R, r->ctl, cur, b == 0 ? 1 : 0, r->spillw, r->spill2, r->counters);
         LAUNCH(k_bin, r->flat_blocks / 2, RT_BIN_BLOCK, R, r->ctl, cur, b == 0 ? 1 : 0);
         if (S.env_cond) LAUNCHK(RT_KID_SHADE, (k_shade<false, true>), r->flat_blocks * 256 / RT_SHADE_BLOCK, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
         else LAUNCHK(RT_KID_SHADE, (k_shade<false, false>), r->flat_blocks * 256 / RT_SHADE_BLOCK, RT_SHADE_BLOCK, S, R, r->ctl, cur, 0);
-        LAUNCHK(RT_KID_CONNECT, k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spill4, r->spill2, r->counters);
+        LAUNCHK(RT_KID_CONNECT, k_connect<false>, r->trav_blocks, RT_BLOCK, S, R, r->ctl, r->spillw, r->spill2, r->counters);
     }
     LAUNCH(k_ctl_final, 1, 1, r->ctl);
     LAUNCHK(RT_KID_ACCUMULATE, k_mlt_chain, chains, 64, S, R, r->film, r->filter, chains, seed, first_sample);

@@ -5,10 +5,16 @@
 //              reference tree, so "first visited wins ties" (Geometry.h:449) becomes
 //              "lowest index wins".  One lane fetches one record as 4 x dwordx4.
 //   trishade : 64 B / triangle (vertex normals, uvs, area), same order; only read at a hit.
-//   nodes4   : 128 B (one L2 line) per 4-wide node: SoA child boxes + child refs.  What the builders produce; the walk reads
-//   nodesq   : 64 B per 4-wide node, the same tree with the child boxes on a 256-step grid of the node's own box, rounded
-//              outwards.  A lane fetches a node as 4 x dwordx4 instead of 7: the traversal kernels are bound by the number of
-//              divergent load instructions per step, not by arithmetic.
+//   nodes4   : 128 B (one L2 line) per 4-wide node: SoA child boxes + child refs.  What the builders produce (host and device,
+//              byte for byte the same); every child box is the box of a reference node.  Not read by the walk.
+//   nodes8   : 80 B per 8-wide node, what the walk reads: derived on the device from nodes4 (walk_tree.hip) by opening the
+//              largest children of a 4-wide node until eight slots are taken.  Child boxes sit on a 256-step grid of the node's
+//              own box (one byte per plane, rounded outwards), children are numbered consecutively (child_base + rank among
+//              the inner slots) and so are the node's leaf triangles (tri_base + offset in trisw), so a node needs no child
+//              references: 5 x dwordx4 per 8 children.  The traversal kernels are bound by the number of divergent load
+//              instructions per ray; the 4-wide nodes of round 2 took 4 loads per 4 children.
+//   trisw    : the 64-B triangle records once more, in the order the 8-wide tree's leaves name them (level, node, slot); the
+//              word that is orig_id in `tris` holds the triangle's DFS rank, which the walk reports and breaks ties with.
 //   gate     : 32 B per triangle: the reference box whose rayAABB decides whether upstream tests that triangle at all
 //              (its leaf's box, or the parent's for a single-triangle leaf); read once per ray, for the hit it reports.
 //   nodes2   : 48 B per node of the reference-topology binary tree (validation / fallback walk).
@@ -25,9 +31,11 @@
 // centroid on one side (Geometry.h:426): on the bench scene some twenty leaves of 8-16 large triangles (walls, floor) whose
 // box nearly every ray crosses.  Longer leaves are cut into small subtrees of slots, each bounded by its own triangles:
 // 16 -> 4 took the triangle tests per ray from 9.4 to 6.6 and added one node visit (23.3 -> 24.3): +5 % Mrays/s (3, 6, 8 the same).
+// Since round 3 at most 3: the 8-wide walk nodes name a leaf slot's triangles by three mask bits (DNode8::meta).
 #ifndef RT_LEAF_MAX
-#define RT_LEAF_MAX 4u
+#define RT_LEAF_MAX 3u
 #endif
+static_assert(RT_LEAF_MAX >= 1u && RT_LEAF_MAX <= 3u, "a leaf slot holds 1-3 triangles: DNode8::meta has three bits for them, a DNode4 child reference four");
 #define RT_LEAF_FIRST_MASK 0x07FFFFFFu
 static inline uint32_t rt_make_leaf_ref(uint32_t first, uint32_t count) { return RT_REF_LEAF | ((count - 1u) << 27) | first; }
 
@@ -49,11 +57,19 @@ struct DNode4 {      // 128 B
     uint32_t child[4];
     uint32_t pad[4];
 };
-struct DNodeQ {      // 64 B: child k's box is org + q * scale per axis, q = byte k of the plane words (lo rounded down, hi up)
-    float org[3]; float scale_x;
-    float scale_y, scale_z; uint32_t lox, loy;
-    uint32_t loz, hix, hiy, hiz;
-    uint32_t child[4];   // as DNode4::child; the walk tells unused slots by RT_REF_EMPTY here
+// 80 B, five 16-B rows.  Slot s's box is org + q * 2^e per axis, q = byte s of the two plane words (lo rounded down, hi up).
+// meta byte of slot s: 0 = unused; inner child: 0x20 | (24 + s); leaf: (unary triangle count 1 / 3 / 7) << 5 | offset, the
+// slot's triangles being trisw[tri_base + offset ...].  A slot that passes the box test ORs (meta >> 5) << (meta & 31) into
+// the node's hit mask -- bits 24-31 inner children, bits 0-23 triangles -- after the low three bits of an inner child's
+// index were XORed with the ray's octant: children sit in the slot whose octant their centre lies in (as far as a greedy
+// assignment manages), so "highest bit first" visits them roughly front to back without a sort (the compressed wide BVH of
+// Ylitie, Karras & Laine 2017).  Inner child in slot s = node child_base + popcount(imask & ((1 << s) - 1)).
+struct DNode8 {
+    float org[3]; uint32_t exp_imask;    // int8 ex | int8 ey << 8 | int8 ez << 16 | imask << 24
+    uint32_t child_base, tri_base, meta[2];
+    uint32_t lox[2], loy[2];
+    uint32_t loz[2], hix[2];
+    uint32_t hiy[2], hiz[2];
 };
 struct DGate { float lo[3], pad0, hi[3], pad1; };   // 32 B
 struct DNode2 {      // 48 B, reference-topology node (BVHNode, Geometry.h:290): leaf <=> left < 0 && right < 0
@@ -61,7 +77,7 @@ struct DNode2 {      // 48 B, reference-topology node (BVHNode, Geometry.h:290):
     float hi[3]; int32_t right;
     int32_t first, count, pad0, pad1;
 };
-static_assert(sizeof(DTri) == 64 && sizeof(DTriShade) == 64 && sizeof(DNode4) == 128 && sizeof(DNode2) == 48 && sizeof(DNodeQ) == 64 && sizeof(DGate) == 32, "layout");
+static_assert(sizeof(DTri) == 64 && sizeof(DTriShade) == 64 && sizeof(DNode4) == 128 && sizeof(DNode2) == 48 && sizeof(DNode8) == 80 && sizeof(DGate) == 32, "layout");
 
 struct DMaterial {   // 80 B
     uint32_t type;       // RT_MAT_*
@@ -96,16 +112,17 @@ struct DScene {
     const DTri* tris;
     const DTriShade* trishade;
     const DNode4* nodes4;
-    const DNodeQ* nodesq;
+    const DNode8* nodes8;
+    const DTri* trisw;
     const DGate* gate;
     const DNode2* nodes2;
     const DMaterial* mats;
     const DTexture* tex;
     const float* texels;
     const DLight* lights;
-    uint32_t n_tris, n_lights, n_nodes4, n_nodes2;
+    uint32_t n_tris, n_lights, n_nodes4, n_nodes2, n_nodes8;
     uint32_t root_ref;        // RT_REF_EMPTY for an empty scene, else node 0
-    uint32_t max_stack4, max_stack2;
+    uint32_t walk_stack, max_stack2;   // most 8-byte entries a walk over nodes8 can have waiting; most words of the reference-order walk
     float abs_max;            // max |coordinate| over the scene, scales the conservative cull pad
     float bg_colour[3];
     uint32_t bg_kind; int32_t bg_tex;

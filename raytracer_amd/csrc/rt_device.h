@@ -14,7 +14,7 @@
 #define RT_TRAV_WAVES 6    // __launch_bounds__ waves/SIMD target of the traversal kernels
 #endif
 #ifndef RT_STACK_LDS
-#define RT_STACK_LDS 24          // stack entries per lane kept in LDS (24 KB per 256-thread block)
+#define RT_STACK_LDS 12          // 8-byte stack entries per lane kept in LDS (24 KB per 256-thread block)
 #endif
 #define RT_FLT_MAX 3.402823466e+38f
 #define RT_INF __builtin_inff()
@@ -72,49 +72,35 @@ __device__ __host__ __forceinline__ float rt_rng_next(Rng& r) {
     return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
 
-// ---- traversal stack: the first RT_STACK_LDS entries of each lane live in LDS (lane-interleaved, so a
-// push/pop of the whole wave touches 64 consecutive banks); deeper entries spill to a per-launch HBM array.
-#ifndef RT_STACK_KEYS
-#define RT_STACK_KEYS 0   // measured: the extra LDS plane costs more occupancy than the pop-time cull saves
-#endif
-// An entry is a child reference plus (RT_STACK_KEYS) the padded entry distance of its box, so a subtree that became
-// irrelevant while it waited on the stack is dropped at pop time without fetching its node / triangles.  References
-// and keys live in two lane-interleaved 32-bit planes (LDS: [2][RT_STACK_LDS][RT_BLOCK]).
-#define RT_STACK_WORDS ((RT_STACK_KEYS ? 2 : 1) * RT_STACK_LDS * RT_BLOCK)
-typedef __attribute__((address_space(3))) uint32_t rt_lds_u32;  // explicit LDS address space: keeps pops ds_read, not flat_load
+// ---- traversal stack: the first RT_STACK_LDS entries of each lane live in LDS (lane-interleaved 8-byte entries, so a
+// push/pop of the whole wave is one conflict-free ds_write_b64 / ds_read_b64); deeper entries spill to a per-launch HBM array.
+// An entry is a group of the 8-wide walk (rt_node_eval): {child_base, hit bits << 24 | imask} -- the children of one node
+// that still have to be entered -- or {tri_base, triangle bits} -- the triangles of one node that still have to be tested.
+typedef uint32_t rt_u2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) rt_u2 rt_lds_u2;  // explicit LDS address space: keeps pops ds_read, not flat_load
+#define RT_STACK_WORDS (2 * RT_STACK_LDS * RT_BLOCK)
+#define RT_SPILL_WORDS(walk_stack) ((walk_stack) > (uint32_t)RT_STACK_LDS ? ((walk_stack) - (uint32_t)RT_STACK_LDS) * 2u : 0u)   // per lane
 struct TravStack {
-    rt_lds_u32* lds;   // &lds_stack[threadIdx.x]
-    uint32_t* glob;    // &spill[global thread id], may be null when the scene's bound fits LDS
+    rt_lds_u2* lds;    // &lds_stack[threadIdx.x]
+    rt_u2* glob;       // &spill[global thread id], may be null when the scene's bound fits LDS
     uint32_t gstride;  // total threads of the launch
-    uint32_t gkeys;    // offset (in words) of the key plane inside the spill array
-    __device__ __forceinline__ void put(uint32_t sp, uint32_t v, float key) {
-        if (sp < RT_STACK_LDS) {
-            lds[sp * RT_BLOCK] = v;
-            if (RT_STACK_KEYS) lds[(RT_STACK_LDS + sp) * RT_BLOCK] = __float_as_uint(key);
-        } else {
-            size_t o = (size_t)(sp - RT_STACK_LDS) * gstride;
-            glob[o] = v;
-            if (RT_STACK_KEYS) glob[o + gkeys] = __float_as_uint(key);
-        }
+    __device__ __forceinline__ void put(uint32_t sp, uint32_t b, uint32_t m) {
+        rt_u2 v; v.x = b; v.y = m;
+        if (sp < RT_STACK_LDS) lds[sp * RT_BLOCK] = v;
+        else glob[(size_t)(sp - RT_STACK_LDS) * gstride] = v;
     }
-    __device__ __forceinline__ uint32_t get(uint32_t sp, float& key) const {
+    __device__ __forceinline__ void get(uint32_t sp, uint32_t& b, uint32_t& m) const {
         // the LDS read is unconditional (clamped index) so that it stays a ds_read: with one load per branch the
         // compiler sinks both into a single flat_load, which is slower than LDS for the common case
         const uint32_t i = sp < RT_STACK_LDS ? sp : RT_STACK_LDS - 1u;
-        uint32_t v = lds[i * RT_BLOCK];
-        key = RT_STACK_KEYS ? __uint_as_float(lds[(RT_STACK_LDS + i) * RT_BLOCK]) : -RT_INF;
-        if (sp >= RT_STACK_LDS) {
-            size_t o = (size_t)(sp - RT_STACK_LDS) * gstride;
-            v = glob[o];
-            if (RT_STACK_KEYS) key = __uint_as_float(glob[o + gkeys]);
-        }
-        return v;
+        rt_u2 v = lds[i * RT_BLOCK];
+        if (sp >= RT_STACK_LDS) v = glob[(size_t)(sp - RT_STACK_LDS) * gstride];
+        b = v.x; m = v.y;
     }
 };
-#define RT_TRAV_STACK_INIT(st, lds_stack, spill4, gtid, gstride, max_stack4)                    \
-    TravStack st;                                                                             \
-    st.lds = (rt_lds_u32*)(lds_stack + threadIdx.x); st.glob = spill4 ? spill4 + gtid : nullptr; st.gstride = gstride; \
-    st.gkeys = (max_stack4 > RT_STACK_LDS ? (max_stack4 - RT_STACK_LDS) : 0u) * gstride;
+#define RT_TRAV_STACK_INIT(st, lds_stack, spillw, gtid, gstride)                                    \
+    TravStack st;                                                                                 \
+    st.lds = (rt_lds_u2*)lds_stack + threadIdx.x; st.glob = spillw ? (rt_u2*)spillw + gtid : nullptr; st.gstride = gstride;
 
 struct HitRec { float t, u, v; uint32_t rank; };
 
@@ -283,199 +269,194 @@ __device__ bool rt_walk_exact(const DScene& S, f3 o, f3 dir, float maxT, HitRec&
     return true;
 }
 
-#define RT_CSWAP(ka, ra, kb, rb)                                  \
-    {                                                             \
-        bool s_ = kb < ka;                                        \
-        float tk_ = s_ ? kb : ka; kb = s_ ? ka : kb; ka = tk_;    \
-        uint32_t tr_ = s_ ? rb : ra; rb = s_ ? ra : rb; ra = tr_; \
-    }
-
-// ---- 4-wide ordered walk, one step at a time.  The per-lane state lives in a Walk so that a wave can keep
-// stepping the rays it has while lanes whose ray finished are handed new ones (rt_persistent_walk below).
+// ---- the 8-wide walk, one step at a time.  The per-lane state lives in a Walk so that a wave can keep stepping the
+// rays it has while lanes whose ray finished are handed new ones (rt_persistent_walk below).
 //
-// Closest hit: children sorted near-to-far, subtrees skipped when their box, padded by `pad` (a spatial slack of
-// ~1000 ulp of the largest coordinate, expressed in t per axis), cannot hold a hit in [0, best.t].  Any hit: the
-// reference's box rule (tentry <= texit && !(tentry > maxT)) plus a padded "entirely behind the origin" skip, any
-// order.  Skipping only uses the padded interval; whether a child is *entered* is always the reference's own
-// test on the reference's own box.
+// The tests are CONSERVATIVE ONLY.  Upstream's answer is min (t, DFS rank) over the triangles that pass rayIntersect AND whose
+// ancestor boxes all pass rayAABB; for a tame ray the box test is monotone under containment (section 3 of DESIGN.md), so the
+// second condition is "the triangle's gate box passes" (DScene::gate).  The walk may therefore use any tree, any boxes and any
+// arithmetic that never skip a true hit nearer than the best so far -- here the 8-wide nodes of walk_tree.hip, their child
+// boxes on a 256-step grid of the node's box, rounded outwards, grown by the slack `pad`, evaluated with one fma per plane --
+// as long as the hit it ends with is then checked against its gate box with upstream's own expression (rt_settle): if that
+// check fails, which takes a hit within rounding of its gate box's surface, the ray is walked again by rt_walk_exact.
+//   plane in t:  (org + q * s - o) * inv -+ pad  =  q * (s * inv) + ((org - o) * inv -+ pad)  =  fma(q, A, B)
+// Rounding: org - o, B and the final fma round once each, <= 3 * 2^-24 * 3 M |1/dir|, inside the slack's budget (below);
+// s is a power of two, so A = ldexp(inv, e) is exact.
+//
 // Slack of the conservative culls, as a fraction of the largest coordinate in play (scene extent, ray origin): a box is grown
 // by delta = RT_PAD_SCALE * M before the walk may skip it.  What the slack has to cover: an accepted
 // hit's point p = o + dir * t lies inside its triangle -- hence inside every box around it -- up to the rounding of the
 // plane equation, of p and of the barycentric test, together < 2^-19 M whatever the triangle's shape; expressing the box
 // planes in t adds 8 * 2^-24 M |1/dir|.  2^-17 M (128 ulp) is three times that bound.  Round 1 used 2^-14: for rays nearly
 // parallel to an axis the pad in t is delta * |1/dir|, and the eight-fold larger pad kept whole subtrees behind the origin
-// and beyond the best hit alive (+4.9 % Mrays/s on the bench scene from this constant and the per-axis any-hit pad below).
+// and beyond the best hit alive (+4.9 % Mrays/s on the bench scene).  rt_settle only catches a hit the walk should not have
+// reported (its gate box fails); a true hit culled by too small a pad is never seen at run time: lowering RT_PAD_SCALE needs
+// the strained-ray, aimed-ray and scaled-scene tests of tests/test_intersect_gpu.py to pass.
 #ifndef RT_PAD_SCALE
 #define RT_PAD_SCALE 7.62939453125e-06f   // 2^-17
 #endif
-// Any-hit walks test "entirely behind the origin" with the per-axis pad as well (3 adds + 2 mins per child more than round 1's
-// scalar delta * max |1/dir|, which let axis-parallel shadow rays walk everything behind them: k_connect -6 %).
+static_assert(RT_PAD_SCALE >= 7.62939453125e-06f, "the cull slack was derived and tested for 2^-17 of the largest coordinate; see the comment above");
+// What a lane holds: `cur`, a group of inner children still to enter {cb = the node's child_base, cm = hit bits << 24 | imask}
+// (or, while `pend` is taken, a group of triangles that waits its turn; cm == 0: nothing, and then the stack is empty too),
+// and `pend`, the triangles being tested {pb = the node's tri_base, pm = one bit per triangle}.  A lane that meets triangles
+// does not stop walking: they are set aside in pend and the lane goes on with the next node, so that it has work for either
+// kind of wave step (Aila & Laine's speculative traversal); what that costs is that the nodes walked meanwhile were not
+// culled by the hit the postponed triangles may hold.
 struct Walk {
     f3 o, dir, inv;
     f3 pad;        // the slack in t per axis: delta * |1/dir|
     float maxT;        // any hit
     HitRec best;       // closest hit so far; any hit: best.rank = the blocker that was found
-    uint32_t cur, sp;
-    uint32_t pend;     // rt_vote_step: the leaf set aside while the lane walks on (RT_REF_EMPTY: none)
+    uint32_t cb, cm;   // cur
+    uint32_t pb, pm;   // pend
+    uint32_t sp;
+    uint32_t q4;       // the ray's octant (bit a set where dir is non-negative on axis a) in each of the four bytes
     uint32_t mx, my, mz;   // all ones where 1/dir is negative on that axis, else 0: picks a node's hi planes as the near planes
     bool occluded;
-    bool wide;         // this item went through the 4-wide walk: its answer still has to pass rt_settle
+    bool wide;         // this item went through the wide walk: its answer still has to pass rt_settle
 };
+__device__ __forceinline__ bool rt_cur_is_nodes(const Walk& w) { return (w.cm >> 24) != 0u; }
+__device__ __forceinline__ bool rt_cur_is_tris(const Walk& w) { return w.cm != 0u && (w.cm >> 24) == 0u; }
+__device__ __forceinline__ bool rt_walk_done(const Walk& w) { return w.cm == 0u && w.pm == 0u; }
+__device__ __forceinline__ void rt_walk_signs(Walk& w) {
+    w.mx = w.inv.x < 0.0f ? 0xFFFFFFFFu : 0u; w.my = w.inv.y < 0.0f ? 0xFFFFFFFFu : 0u; w.mz = w.inv.z < 0.0f ? 0xFFFFFFFFu : 0u;
+    w.q4 = ((w.inv.x < 0.0f ? 0u : 1u) | (w.inv.y < 0.0f ? 0u : 2u) | (w.inv.z < 0.0f ? 0u : 4u)) * 0x01010101u;
+}
 __device__ __forceinline__ void rt_walk_init(const DScene& S, Walk& w, f3 o, f3 dir, f3 inv, float maxT) {
     float scale = fmaxf(S.abs_max, fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))));
     float delta = scale * RT_PAD_SCALE;
     w.o = o; w.dir = dir; w.inv = inv;
     w.pad = mk3(delta * fabsf(inv.x), delta * fabsf(inv.y), delta * fabsf(inv.z));
     w.maxT = maxT;
-    w.mx = inv.x < 0.0f ? 0xFFFFFFFFu : 0u; w.my = inv.y < 0.0f ? 0xFFFFFFFFu : 0u; w.mz = inv.z < 0.0f ? 0xFFFFFFFFu : 0u;
-    w.cur = S.root_ref; w.sp = 0; w.pend = RT_REF_EMPTY; w.occluded = false; w.wide = true;
+    rt_walk_signs(w);
+    w.cb = 0u; w.cm = 1u << 24;   // "one child left to enter below child_base 0": node 0, whatever the octant
+    w.pb = 0u; w.pm = 0u; w.sp = 0u; w.occluded = false; w.wide = true;
 }
-// Box tests of one 4-wide node: pushes the passing children but the nearest, which becomes w.cur (returns true).
-//
-// The tests are CONSERVATIVE ONLY.  Upstream's answer is min (t, DFS rank) over the triangles that pass rayIntersect AND whose
-// ancestor boxes all pass rayAABB; for a tame ray the box test is monotone under containment (section 3 of DESIGN.md), so the
-// second condition is "the triangle's gate box passes" (DScene::gate).  The walk may therefore use any boxes and any
-// arithmetic that never skip a true hit nearer than the best so far -- here the child boxes on a 256-step grid of the node's
-// box, rounded outwards, grown by the slack `pad`, evaluated with one fma per plane -- as long as the hit it ends with is then
-// checked against its gate box with upstream's own expression (rt_settle): if that check fails, which takes a hit within
-// rounding of its gate box's surface, the ray is walked again by rt_walk_exact.
-//   plane in t:  (org + q * s - o) * inv -+ pad  =  q * (s * inv) + ((org - o) * inv -+ pad)  =  fma(q, A, B)
-// Rounding: org - o, B and the final fma round once each, <= 3 * 2^-24 * 3 M |1/dir|, inside the slack's budget (rt_walk_init).
-// (Writing the slab arithmetic on child pairs as v_pk_* measured slower in round 1; the build passes -fno-slp-vectorize.)
-#ifndef RT_POP_FAST
-#define RT_POP_FAST 1
-#endif
 __device__ __forceinline__ uint32_t rt_bfi(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); }   // v_bfi_b32
 __device__ __forceinline__ float rt_ub0(uint32_t v) { return (float)(v & 255u); }            // v_cvt_f32_ubyte0..3
 __device__ __forceinline__ float rt_ub1(uint32_t v) { return (float)((v >> 8) & 255u); }
 __device__ __forceinline__ float rt_ub2(uint32_t v) { return (float)((v >> 16) & 255u); }
 __device__ __forceinline__ float rt_ub3(uint32_t v) { return (float)(v >> 24); }
+__device__ __forceinline__ void rt_pop(Walk& w, TravStack& st) {
+    if (w.sp == 0u) { w.cm = 0u; return; }
+    --w.sp;
+    st.get(w.sp, w.cb, w.cm);
+}
+// cur after a pop: triangles move on to pend as soon as pend is free
+__device__ __forceinline__ void rt_settle_refs(Walk& w, TravStack& st) {
+    if (rt_cur_is_tris(w) && w.pm == 0u) { w.pb = w.cb; w.pm = w.cm; rt_pop(w, st); }
+}
+// One node: enters the next child of cur (the highest hit bit: children sit in octant order, see DNode8), tests its eight
+// slots and files what passed -- inner children become cur, triangles go to pend (or wait), what was left of the old cur
+// goes onto the stack.  At most two pushes and no sort; a node is five 16-byte loads.
 template <bool ANY>
-__device__ __forceinline__ bool rt_node_eval(const DScene& S, Walk& w, TravStack& st) {
-    const char* nb = reinterpret_cast<const char*>(S.nodesq);
-    const uint32_t base = w.cur << 6;   // < 2^31: the host caps the wide tree at 2^25 nodes
-    const float4 h0 = *reinterpret_cast<const float4*>(nb + base);
-    const uint4 h1 = *reinterpret_cast<const uint4*>(nb + (base + 16u));
-    const uint4 h2 = *reinterpret_cast<const uint4*>(nb + (base + 32u));
-    const uint4 ch = *reinterpret_cast<const uint4*>(nb + (base + 48u));
-    const float ax = h0.w * w.inv.x, ay = __uint_as_float(h1.x) * w.inv.y, az = __uint_as_float(h1.y) * w.inv.z;
-    const float dx = h0.x - w.o.x, dy = h0.y - w.o.y, dz = h0.z - w.o.z;
+__device__ __forceinline__ void rt_node_eval(const DScene& S, Walk& w, TravStack& st) {
+    const uint32_t k = 31u - (uint32_t)__clz((int)w.cm);
+    const uint32_t rem = w.cm & ~(1u << k);
+    const uint32_t slot = (k ^ w.q4) & 7u;
+    const uint32_t node = w.cb + (uint32_t)__popc(rem & ((1u << slot) - 1u));   // the mask only reaches imask: hit bits sit at 24 and above
+    const char* nb = reinterpret_cast<const char*>(S.nodes8);
+    const uint32_t base = node * 80u;   // < 2^32: the tree is capped at 2^25 nodes
+    const float4 r0 = *reinterpret_cast<const float4*>(nb + base);
+    const uint4 r1 = *reinterpret_cast<const uint4*>(nb + (base + 16u));   // child_base, tri_base, meta[2]
+    const uint4 r2 = *reinterpret_cast<const uint4*>(nb + (base + 32u));   // lox[2] loy[2]
+    const uint4 r3 = *reinterpret_cast<const uint4*>(nb + (base + 48u));   // loz[2] hix[2]
+    const uint4 r4 = *reinterpret_cast<const uint4*>(nb + (base + 64u));   // hiy[2] hiz[2]
+    const uint32_t hw = __float_as_uint(r0.w);
+    const float ax = ldexpf(w.inv.x, (int)(hw << 24) >> 24), ay = ldexpf(w.inv.y, (int)(hw << 16) >> 24), az = ldexpf(w.inv.z, (int)(hw << 8) >> 24);
+    const float dx = r0.x - w.o.x, dy = r0.y - w.o.y, dz = r0.z - w.o.z;
     const float blx = __builtin_fmaf(dx, w.inv.x, -w.pad.x), bhx = __builtin_fmaf(dx, w.inv.x, w.pad.x);
     const float bly = __builtin_fmaf(dy, w.inv.y, -w.pad.y), bhy = __builtin_fmaf(dy, w.inv.y, w.pad.y);
     const float blz = __builtin_fmaf(dz, w.inv.z, -w.pad.z), bhz = __builtin_fmaf(dz, w.inv.z, w.pad.z);
-    const uint32_t nx = rt_bfi(w.mx, h2.y, h1.z), fx = rt_bfi(w.mx, h1.z, h2.y);
-    const uint32_t ny = rt_bfi(w.my, h2.z, h1.w), fy = rt_bfi(w.my, h1.w, h2.z);
-    const uint32_t nz = rt_bfi(w.mz, h2.w, h2.x), fz = rt_bfi(w.mz, h2.x, h2.w);
     const float limit = ANY ? w.maxT : w.best.t;
-    float k0, k1, k2, k3;
-#define RT_SLOT(UB, REF, KEY)                                                                               \
-    {                                                                                                      \
-        float lo_ = fmaxf(__builtin_fmaf(UB(nx), ax, blx), fmaxf(__builtin_fmaf(UB(ny), ay, bly), __builtin_fmaf(UB(nz), az, blz))); \
-        float hi_ = fminf(__builtin_fmaf(UB(fx), ax, bhx), fminf(__builtin_fmaf(UB(fy), ay, bhy), __builtin_fmaf(UB(fz), az, bhz))); \
-        bool pass = (fmaxf(lo_, 0.0f) <= fminf(hi_, limit)) && (REF != RT_REF_EMPTY);                      \
-        KEY = pass ? lo_ : RT_INF;                                                                         \
+    uint32_t hit = 0u;
+    // four slots per pass: the near / far plane bytes by the ray's sign, and per slot the bits it stands for and where they go
+#define RT_SLOT(UB, SH)                                                                                                       \
+    {                                                                                                                         \
+        const float lo_ = fmaxf(__builtin_fmaf(UB(nx), ax, blx), fmaxf(__builtin_fmaf(UB(ny), ay, bly), __builtin_fmaf(UB(nz), az, blz))); \
+        const float hi_ = fminf(__builtin_fmaf(UB(fx), ax, bhx), fminf(__builtin_fmaf(UB(fy), ay, bhy), __builtin_fmaf(UB(fz), az, bhz))); \
+        const bool pass = fmaxf(lo_, 0.0f) <= fminf(hi_, limit);                                                               \
+        const uint32_t b_ = ((bits >> SH) & 255u) << ((idx >> SH) & 255u);                                                    \
+        hit |= pass ? b_ : 0u;                                                                                                \
     }
-    RT_SLOT(rt_ub0, ch.x, k0)
-    RT_SLOT(rt_ub1, ch.y, k1)
-    RT_SLOT(rt_ub2, ch.z, k2)
-    RT_SLOT(rt_ub3, ch.w, k3)
+#define RT_HALF(LOX, LOY, LOZ, HIX, HIY, HIZ, META)                                                                           \
+    {                                                                                                                         \
+        const uint32_t nx = rt_bfi(w.mx, HIX, LOX), fx = rt_bfi(w.mx, LOX, HIX);                                             \
+        const uint32_t ny = rt_bfi(w.my, HIY, LOY), fy = rt_bfi(w.my, LOY, HIY);                                             \
+        const uint32_t nz = rt_bfi(w.mz, HIZ, LOZ), fz = rt_bfi(w.mz, LOZ, HIZ);                                             \
+        const uint32_t inner = ((META & (META << 1)) & 0x10101010u) >> 4;   /* 1 in the bytes of inner children (index 24-31) */ \
+        const uint32_t idx = (META ^ ((inner * 7u) & w.q4)) & 0x1F1F1F1Fu;  /* their index XOR the ray's octant */              \
+        const uint32_t bits = (META >> 5) & 0x07070707u;                                                                      \
+        RT_SLOT(rt_ub0, 0) RT_SLOT(rt_ub1, 8) RT_SLOT(rt_ub2, 16) RT_SLOT(rt_ub3, 24)                                         \
+    }
+    RT_HALF(r2.x, r2.z, r3.x, r3.z, r4.x, r4.z, r1.z)
+    RT_HALF(r2.y, r2.w, r3.y, r3.w, r4.y, r4.w, r1.w)
+#undef RT_HALF
 #undef RT_SLOT
-    uint32_t r0 = ch.x, r1 = ch.y, r2 = ch.z, r3 = ch.w;
-    if (!ANY) {
-#ifndef RT_SORT_SWAPS
-#define RT_SORT_SWAPS 5
-#endif
-        RT_CSWAP(k0, r0, k1, r1) RT_CSWAP(k2, r2, k3, r3) RT_CSWAP(k0, r0, k2, r2)   // the nearest child is in slot 0 now
-        if (RT_SORT_SWAPS >= 4) RT_CSWAP(k1, r1, k3, r3)
-        if (RT_SORT_SWAPS >= 5) RT_CSWAP(k1, r1, k2, r2)
-    } else {  // no order needed: compact the passing children to the front
-        if (!(k2 < RT_INF)) { k2 = k3; r2 = r3; k3 = RT_INF; }
-        if (!(k1 < RT_INF)) { k1 = k2; r1 = r2; k2 = k3; r2 = r3; k3 = RT_INF; }
-        if (!(k0 < RT_INF)) { k0 = k1; r0 = r1; k1 = k2; r1 = r2; k2 = k3; r2 = r3; k3 = RT_INF; }
-    }
-    if (!RT_STACK_KEYS && __ballot(w.sp + 3u > (uint32_t)RT_STACK_LDS) == 0) {
-        // every lane has room in LDS for three more: store unconditionally, advance by the predicate
-        st.lds[w.sp * RT_BLOCK] = r3; w.sp += (k3 < RT_INF) ? 1u : 0u;
-        st.lds[w.sp * RT_BLOCK] = r2; w.sp += (k2 < RT_INF) ? 1u : 0u;
-        st.lds[w.sp * RT_BLOCK] = r1; w.sp += (k1 < RT_INF) ? 1u : 0u;
+    const uint32_t gm = hit & 0xFF000000u, tm = hit & 0x00FFFFFFu;
+    const bool pend_free = w.pm == 0u;
+    w.pb = pend_free ? r1.y : w.pb; w.pm = pend_free ? tm : w.pm;
+    const bool x1 = gm != 0u;                    // inner children to enter: they become cur
+    const bool x2 = tm != 0u && !pend_free;      // triangles that have to wait for pend
+    const bool x3 = rem >= (1u << 24);           // the old cur has children left
+    const bool push_rem = x3 && (x1 || x2), push_tri = x2 && x1;
+    if (__ballot(w.sp + 2u > (uint32_t)RT_STACK_LDS) == 0) {
+        // every lane has room in LDS for two more: store unconditionally, advance by the predicate
+        rt_u2 v; v.x = w.cb; v.y = rem;
+        st.lds[w.sp * RT_BLOCK] = v; w.sp += push_rem ? 1u : 0u;
+        v.x = r1.y; v.y = tm;
+        st.lds[w.sp * RT_BLOCK] = v; w.sp += push_tri ? 1u : 0u;
     } else {
-        if (k3 < RT_INF) st.put(w.sp++, r3, k3);
-        if (k2 < RT_INF) st.put(w.sp++, r2, k2);
-        if (k1 < RT_INF) st.put(w.sp++, r1, k1);
+        if (push_rem) st.put(w.sp++, w.cb, rem);
+        if (push_tri) st.put(w.sp++, r1.y, tm);
     }
-    if (k0 < RT_INF) { w.cur = r0; return true; }
-    return false;
+    const uint32_t ob = w.cb;
+    w.cb = x1 ? r1.x : (x2 ? r1.y : ob);
+    w.cm = x1 ? (gm | (hw >> 24)) : (x2 ? tm : (x3 ? rem : 0u));
+    if (!(x1 || x2 || x3)) { rt_pop(w, st); rt_settle_refs(w, st); }
 }
-// pop, dropping entries whose (padded) entry distance now lies beyond the best hit; false = stack empty
+// One triangle of pend.  Returns true when an any-hit walk found its blocker.
 template <bool ANY>
-__device__ __forceinline__ bool rt_pop(Walk& w, TravStack& st) {
-    if (!RT_STACK_KEYS && RT_POP_FAST) {
-        if (w.sp == 0) return false;
-        --w.sp;
-        float key;
-        w.cur = st.get(w.sp, key);
-        return true;
+__device__ __forceinline__ bool rt_tri_eval_step(const DScene& S, Walk& w, TravStack& st) {
+    const uint32_t j = (uint32_t)__ffs((int)w.pm) - 1u;
+    w.pm &= w.pm - 1u;
+    const float4* q = reinterpret_cast<const float4*>(S.trisw + (w.pb + j));
+    const float4 a = q[0], b = q[1], c = q[2], e = q[3];
+    float t, u, v;
+    if (rt_tri_eval_all(a, b, c, e, w.o, w.dir, t, u, v)) {
+        const uint32_t rank = __float_as_uint(e.z);   // trisw keeps the DFS rank where tris keeps orig_id
+        if (ANY) { if (t < w.maxT) { w.occluded = true; w.best.rank = rank; return true; } }
+        else if (t < w.best.t || (t == w.best.t && rank < w.best.rank)) { w.best.t = t; w.best.u = u; w.best.v = v; w.best.rank = rank; }
     }
-    while (w.sp) {
-        float key;
-        uint32_t c = st.get(--w.sp, key);
-        if (ANY || !(key > w.best.t)) { w.cur = c; return true; }
-    }
+    if (w.pm == 0u && rt_cur_is_tris(w)) { w.pb = w.cb; w.pm = w.cm; rt_pop(w, st); }
     return false;
 }
-// One node or one leaf, then a pop.  Returns true when the walk is over (stack empty, or ANY found a blocker).
+// One node or one triangle.  Returns true when the walk is over (nothing left, or ANY found a blocker).
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ bool rt_wide_step(const DScene& S, Walk& w, TravStack& st, uint32_t& c_nodes, uint32_t& c_tris) {
-    const uint32_t cur = w.cur;
-    if (!(cur & RT_REF_LEAF)) {
+    if (rt_cur_is_nodes(w)) {
         if (COUNT) c_nodes++;
-        if (rt_node_eval<ANY>(S, w, st)) return false;
-    } else {
-        uint32_t first = cur & RT_LEAF_FIRST_MASK, cnt = ((cur >> 27) & 15u) + 1u;
-        for (uint32_t k = 0; k < cnt; k++) {
-            float t, u, v;
-            if (COUNT) c_tris++;
-            if (rt_tri_test(S.tris + first + k, w.o, w.dir, t, u, v)) {
-                if (ANY) { if (t < w.maxT) { w.occluded = true; w.best.rank = first + k; return true; } }
-                else if (t < w.best.t || (t == w.best.t && (first + k) < w.best.rank)) {
-                    w.best.t = t; w.best.u = u; w.best.v = v; w.best.rank = first + k;
-                }
-            }
-        }
+        rt_node_eval<ANY>(S, w, st);
+    } else if (w.pm != 0u) {
+        if (COUNT) c_tris++;
+        if (rt_tri_eval_step<ANY>(S, w, st)) return true;
     }
-    return !rt_pop<ANY>(w, st);
+    return rt_walk_done(w);
 }
 
-// ---- the wave-voted step of rt_persistent_walk.  A wave whose lanes are part in nodes and part in leaves pays
+// ---- the wave-voted step of rt_persistent_walk.  A wave whose lanes are part on nodes and part on triangles pays
 // for both code paths in rt_wide_step, each with a fraction of the lanes (PMC: ~26 % of VALU lanes live).  Here
-// the wave runs ONE of the two per step -- box tests for the lanes standing on a node, or one triangle for the
-// lanes standing in a leaf -- whichever serves more lanes per instruction; the others wait a step.
+// the wave runs ONE of the two per step -- box tests for the lanes that have a node to enter, or one triangle for the
+// lanes that hold postponed triangles -- whichever serves more lanes per instruction; the others wait a step.
 // All 64 lanes call it (busy = this lane holds a walk).  Returns true when this lane's walk is over.
 #ifndef RT_VOTE_NUM
-#define RT_VOTE_NUM 1    // nodes go when (lanes on a node) * RT_VOTE_NUM >= (lanes with a leaf) * RT_VOTE_DEN.  With postponed leaves 1:1 is
-#define RT_VOTE_DEN 1    // best (3:2 -1.1 %, 1:2 -1.6 %; "triangles only once 16 / 24 / 32 lanes hold a leaf" -5 % / -4 % / -10 %)
+#define RT_VOTE_NUM 1    // nodes go when (lanes with a node) * RT_VOTE_NUM >= (lanes with triangles) * RT_VOTE_DEN
+#define RT_VOTE_DEN 1
 #endif
-// A lane that reaches a leaf does not stop walking: the leaf is set aside in w.pend and the lane pops on, so that it has work
-// for either kind of step -- box tests for its current node, one triangle of its postponed leaf (Aila & Laine's speculative
-// traversal).  What it costs: the nodes walked meanwhile were not culled by the hit the postponed leaf may hold.  A second
-// leaf met while one is postponed waits in w.cur until the first is done.
-#ifndef RT_POSTPONE
-#define RT_POSTPONE 1
-#endif
-__device__ __forceinline__ bool rt_ref_is_node(uint32_t r) { return !(r & RT_REF_LEAF); }
-__device__ __forceinline__ bool rt_ref_is_leaf(uint32_t r) { return (r & RT_REF_LEAF) && r != RT_REF_EMPTY; }
-template <bool ANY>
-__device__ __forceinline__ void rt_pop_or_none(Walk& w, TravStack& st) { if (!rt_pop<ANY>(w, st)) w.cur = RT_REF_EMPTY; }
-// cur is a node, a leaf that has to wait, or none; a leaf moves to pend as soon as pend is free
-template <bool ANY>
-__device__ __forceinline__ void rt_settle_refs(Walk& w, TravStack& st) {
-    if (rt_ref_is_leaf(w.cur) && w.pend == RT_REF_EMPTY) { w.pend = w.cur; rt_pop_or_none<ANY>(w, st); }
-}
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ bool rt_vote_step(const DScene& S, Walk& w, bool busy, TravStack& st, uint32_t& c_nodes, uint32_t& c_tris) {
-#if RT_POSTPONE
-    const bool innode = busy && rt_ref_is_node(w.cur);
-    const bool inleaf = busy && w.pend != RT_REF_EMPTY;
+    const bool innode = busy && rt_cur_is_nodes(w);
+    const bool inleaf = busy && w.pm != 0u;
     const uint32_t nl = (uint32_t)__popcll(__ballot(inleaf)), nn = (uint32_t)__popcll(__ballot(innode));
     if (nn * (uint32_t)RT_VOTE_NUM >= nl * (uint32_t)RT_VOTE_DEN) {
 #ifdef RT_DBG_WAVESTEPS
@@ -485,54 +466,18 @@ __device__ __forceinline__ bool rt_vote_step(const DScene& S, Walk& w, bool busy
 #ifndef RT_DBG_WAVESTEPS
         if (COUNT) c_nodes++;
 #endif
-        if (!rt_node_eval<ANY>(S, w, st)) rt_pop_or_none<ANY>(w, st);
-        rt_settle_refs<ANY>(w, st);
-        return w.cur == RT_REF_EMPTY && w.pend == RT_REF_EMPTY;
+        rt_node_eval<ANY>(S, w, st);
+        return rt_walk_done(w);
     }
 #ifdef RT_DBG_WAVESTEPS
     if (COUNT) c_tris++;
 #endif
     if (!inleaf) return false;
-    const uint32_t leaf = w.pend;
-    const uint32_t tri = leaf & RT_LEAF_FIRST_MASK, left = (leaf >> 27) & 15u;  // triangles left in the leaf after this one
-    const float4* q = reinterpret_cast<const float4*>(S.tris + tri);
-    float4 a = q[0], b = q[1], c = q[2], e = q[3];
-    float t, u, v;
 #ifndef RT_DBG_WAVESTEPS
     if (COUNT) c_tris++;
 #endif
-    if (rt_tri_eval_all(a, b, c, e, w.o, w.dir, t, u, v)) {
-        if (ANY) { if (t < w.maxT) { w.occluded = true; w.best.rank = tri; return true; } }
-        else if (t < w.best.t || (t == w.best.t && tri < w.best.rank)) { w.best.t = t; w.best.u = u; w.best.v = v; w.best.rank = tri; }
-    }
-    if (left) { w.pend = RT_REF_LEAF | ((left - 1u) << 27) | (tri + 1u); return false; }
-    w.pend = RT_REF_EMPTY;
-    rt_settle_refs<ANY>(w, st);
-    return w.cur == RT_REF_EMPTY && w.pend == RT_REF_EMPTY;
-#else
-    const uint32_t cur = w.cur;
-    const bool inleaf = busy && (cur & RT_REF_LEAF) != 0;
-    const bool innode = busy && !(cur & RT_REF_LEAF);
-    const uint32_t nl = (uint32_t)__popcll(__ballot(inleaf)), nn = (uint32_t)__popcll(__ballot(innode));
-    if (nn * (uint32_t)RT_VOTE_NUM >= nl * (uint32_t)RT_VOTE_DEN) {
-        if (!innode) return false;
-        if (COUNT) c_nodes++;
-        if (rt_node_eval<ANY>(S, w, st)) return false;
-        return !rt_pop<ANY>(w, st);
-    }
-    if (!inleaf) return false;
-    const uint32_t tri = cur & RT_LEAF_FIRST_MASK, left = (cur >> 27) & 15u;  // triangles left in the leaf after this one
-    const float4* q = reinterpret_cast<const float4*>(S.tris + tri);
-    float4 a = q[0], b = q[1], c = q[2], e = q[3];
-    float t, u, v;
-    if (COUNT) c_tris++;
-    if (rt_tri_eval_all(a, b, c, e, w.o, w.dir, t, u, v)) {
-        if (ANY) { if (t < w.maxT) { w.occluded = true; w.best.rank = tri; return true; } }
-        else if (t < w.best.t || (t == w.best.t && tri < w.best.rank)) { w.best.t = t; w.best.u = u; w.best.v = v; w.best.rank = tri; }
-    }
-    if (left) { w.cur = RT_REF_LEAF | ((left - 1u) << 27) | (tri + 1u); return false; }
-    return !rt_pop<ANY>(w, st);
-#endif
+    if (rt_tri_eval_step<ANY>(S, w, st)) return true;
+    return rt_walk_done(w);
 }
 
 // Scene::traverse (Scene.h:118), set-up half: returns true when the result is already known (w.best), false when
@@ -704,20 +649,21 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
                         if (thief && lt_f == j) from = l;
                         bits &= bits - 1ULL;
                     }
-                    uint32_t give = 0;
-                    if (donor) { float key; give = st.get(--w.sp, key); }
+                    uint32_t give_b = 0, give_m = 0;
+                    if (donor) st.get(--w.sp, give_b, give_m);
                     // the ray and what is known about it so far travel by shuffle; non-thieves read themselves
                     const f3 o_ = rt_shfl_f3(w.o, from), d_ = rt_shfl_f3(w.dir, from), i_ = rt_shfl_f3(w.inv, from), p_ = rt_shfl_f3(w.pad, from);
                     const float mt_ = rt_shfl_f(w.maxT, from);
                     const float bt_ = rt_shfl_f(w.best.t, from), bu_ = rt_shfl_f(w.best.u, from), bv_ = rt_shfl_f(w.best.v, from);
                     const uint32_t br_ = (uint32_t)__shfl((int)w.best.rank, (int)from);
-                    const uint32_t sx_ = (uint32_t)__shfl((int)w.mx, (int)from), sy_ = (uint32_t)__shfl((int)w.my, (int)from), sz_ = (uint32_t)__shfl((int)w.mz, (int)from);
-                    const uint32_t it_ = (uint32_t)__shfl((int)item, (int)from), cur_ = (uint32_t)__shfl((int)give, (int)from);
+                    const uint32_t it_ = (uint32_t)__shfl((int)item, (int)from);
+                    const uint32_t cb_ = (uint32_t)__shfl((int)give_b, (int)from), cm_ = (uint32_t)__shfl((int)give_m, (int)from);
                     if (thief) {
                         w.o = o_; w.dir = d_; w.inv = i_; w.pad = p_; w.maxT = mt_;
                         w.best.t = bt_; w.best.u = bu_; w.best.v = bv_; w.best.rank = br_;
-                        w.mx = sx_; w.my = sy_; w.mz = sz_; w.cur = cur_; w.sp = 0; w.pend = RT_REF_EMPTY; w.occluded = false; w.wide = true;
-                        if (RT_POSTPONE && rt_ref_is_leaf(w.cur)) { w.pend = w.cur; w.cur = RT_REF_EMPTY; }
+                        rt_walk_signs(w);
+                        w.cb = cb_; w.cm = cm_; w.pb = 0u; w.pm = 0u; w.sp = 0; w.occluded = false; w.wide = true;
+                        if (rt_cur_is_tris(w)) { w.pb = w.cb; w.pm = w.cm; w.cm = 0u; }
                         item = it_; busy = true; visible = true;
                         if (COUNT) c_mine = 0;
                     }

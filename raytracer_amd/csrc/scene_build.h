@@ -31,6 +31,9 @@ struct HostScene {
     double build_seconds = 0;
     // sizes of the geometry arrays (equal to the vectors' sizes after a host build; a device-side build leaves the vectors empty)
     uint32_t n_tris = 0, n_nodes4 = 0, n_nodes2 = 0;
+    // the tree the walk reads (walk_tree.hip, derived on the device from nodes4 whichever builder made it): 8-wide nodes, the most
+    // 8-byte stack entries a walk can have waiting, and its levels
+    uint32_t n_nodes8 = 0, walk_stack = 0, walk_levels = 0;
 };
 
 // What a device-side build leaves in device memory (hipMalloc'ed; the caller owns the four arrays afterwards).

@@ -32,7 +32,7 @@ struct rt_scene {
     // per-scene scratch for the batched intersect entry points
     DCounters* d_counters = nullptr;
     unsigned long long* d_work = nullptr;   // work-fetch counters
-    uint32_t* d_spill4 = nullptr;           // overflow of the LDS stack (wide walk), may be null
+    uint32_t* d_spillw = nullptr;           // overflow of the LDS stack (wide walk, 8-byte entries), may be null
     uint32_t* d_spill2 = nullptr;           // stack of the reference-order walk
     hipEvent_t scratch_event = nullptr;     // recorded behind the last kernel that used the three arrays above (intersect.hip)
     bool scratch_busy = false;
@@ -46,5 +46,7 @@ struct rt_scene {
     std::mutex mu;
 };
 
+// walk_tree.hip: gate boxes, the 8-wide walk nodes and the walk-ordered triangle records, from nodes4 + tris on the device
+int rt_build_walk_tree(rt_scene* s);
 // shared launch helpers (intersect.hip)
 int rt_scene_persistent_blocks(const rt_scene* s);

@@ -1,0 +1,331 @@
+// walk_tree.hip — the walk's own view of the tree, derived on the device from what the builders leave there.
+//
+// The builders (scene_build.cpp on the host, bvh_build.hip on the device) produce the triangle records in DFS leaf order
+// (`tris`) and the 4-wide collapse of the reference tree with float boxes (`nodes4`), byte for byte the same.  The walk is
+// only required to be conservative -- rt_settle restores upstream's candidate set per ray from the gate box of the hit it
+// reports (rt_device.h) -- so the tree it descends is built for what the traversal kernels are bound
+// by: divergent load instructions per ray.  From nodes4 this file makes
+//   gate   : per triangle, the float box of its leaf slot in nodes4 (the reference box rt_settle tests),
+//   nodes8 : the 8-wide tree, 80 B per node (DNode8, rt_common.h), level by level: a wide node takes the children of a
+//            4-wide node and opens the one with the largest box for as long as the children fit eight slots; slots that
+//            stay free go to the single triangles of multi-triangle leaf slots; a leaf slot is bounded by its own
+//            triangles, an inner slot by its reference box; children are put into the slot whose octant (relative to
+//            the node's centre) they lie in, and numbered consecutively,
+//   trisw  : the triangle records in the order nodes8's leaf slots name them, DFS rank inside.
+// One implementation serves both builders, so device build == host build holds for these arrays by construction
+// (tests/test_bvh_build_gpu.py still compares them).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <math.h>
+
+#include <algorithm>
+#include <utility>
+#include <vector>
+
+#include "rt_device.h"
+#include "scene_dev.h"
+
+namespace {
+
+struct W8Slot { float lo[3], hi[3]; uint32_t ref; };   // ref as in DNode4::child: a nodes4 index, or a leaf (first rank, count)
+
+__device__ __forceinline__ int w8_used(const DNode4& n) {
+    int c = 0;
+    for (int k = 0; k < 4; k++) c += n.child[k] != RT_REF_EMPTY ? 1 : 0;
+    return c;
+}
+__device__ __forceinline__ W8Slot w8_child(const DNode4& n, int k) {
+    W8Slot s;
+    s.lo[0] = n.lox[k]; s.lo[1] = n.loy[k]; s.lo[2] = n.loz[k]; s.hi[0] = n.hix[k]; s.hi[1] = n.hiy[k]; s.hi[2] = n.hiz[k];
+    s.ref = n.child[k];
+    return s;
+}
+__device__ __forceinline__ float w8_area(const W8Slot& s) {
+    const float sx = s.hi[0] - s.lo[0], sy = s.hi[1] - s.lo[1], sz = s.hi[2] - s.lo[2];
+    return ((sx * sy) + (sy * sz) + (sx * sz)) * 2.0f;
+}
+__device__ __forceinline__ bool w8_is_leaf(uint32_t ref) { return (ref & RT_REF_LEAF) != 0u; }
+__device__ __forceinline__ uint32_t w8_leaf_first(uint32_t ref) { return ref & RT_LEAF_FIRST_MASK; }
+__device__ __forceinline__ uint32_t w8_leaf_count(uint32_t ref) { return ((ref >> 27) & 15u) + 1u; }
+__device__ __forceinline__ uint32_t w8_leaf_ref(uint32_t first, uint32_t count) { return RT_REF_LEAF | ((count - 1u) << 27) | first; }
+
+// The up to eight slots of the wide node that stands for 4-wide node `item`, in the order the 4-wide tree lists them.
+__device__ int w8_gather(const DNode4* __restrict__ n4, uint32_t item, W8Slot* s) {
+    int ns = 0;
+    {
+        const DNode4 r = n4[item];
+        for (int k = 0; k < 4; k++)
+            if (r.child[k] != RT_REF_EMPTY) s[ns++] = w8_child(r, k);
+    }
+    for (;;) {   // open the inner slot with the largest box (the first of equals) among those whose children still fit
+        int pick = -1, pick_c = 0; float best = -1.0f;
+        for (int i = 0; i < ns; i++) {
+            if (w8_is_leaf(s[i].ref)) continue;
+            const int c = w8_used(n4[s[i].ref]);
+            if (ns - 1 + c > 8) continue;
+            const float a = w8_area(s[i]);
+            if (a > best) { best = a; pick = i; pick_c = c; }
+        }
+        if (pick < 0) break;
+        const DNode4 e = n4[s[pick].ref];
+        if (pick_c == 0) {   // an inner node without children does not occur; drop it rather than loop
+            for (int i = pick; i + 1 < ns; i++) s[i] = s[i + 1];
+            ns--;
+            continue;
+        }
+        for (int i = ns - 1; i > pick; i--) s[i + pick_c - 1] = s[i];
+        int j = pick;
+        for (int k = 0; k < 4; k++)
+            if (e.child[k] != RT_REF_EMPTY) s[j++] = w8_child(e, k);
+        ns += pick_c - 1;
+    }
+    // slots that are still free go to the triangles of multi-triangle leaf slots, one triangle each, in slot order: every
+    // leaf slot is bounded by its own triangles, so a ray that misses one triangle of a pair no longer tests it
+    for (int i = 0; i < ns && ns < 8; i++) {
+        const uint32_t ref = s[i].ref;
+        if (!w8_is_leaf(ref) || w8_leaf_count(ref) < 2u) continue;
+        for (int k = ns; k > i + 1; k--) s[k] = s[k - 1];
+        s[i + 1] = s[i];
+        s[i].ref = w8_leaf_ref(w8_leaf_first(ref), 1u);
+        s[i + 1].ref = w8_leaf_ref(w8_leaf_first(ref) + 1u, w8_leaf_count(ref) - 1u);
+        ns++;
+    }
+    return ns;
+}
+
+// pass 1 of a level: children that become wide nodes of the next level, and leaf triangles, per wide node
+__global__ void k8_count(uint32_t n_items, const DNode4* __restrict__ n4, const uint32_t* __restrict__ items, uint32_t* __restrict__ cnt_inner,
+                         uint32_t* __restrict__ cnt_tris) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_items) return;
+    if (i == n_items) { cnt_inner[i] = 0u; cnt_tris[i] = 0u; return; }   // the scans' extra entry: its exclusive sum is the level's total
+    W8Slot s[8];
+    const int ns = w8_gather(n4, items[i], s);
+    uint32_t ci = 0, ct = 0;
+    for (int k = 0; k < ns; k++) {
+        if (w8_is_leaf(s[k].ref)) ct += w8_leaf_count(s[k].ref); else ci++;
+    }
+    cnt_inner[i] = ci; cnt_tris[i] = ct;
+}
+
+// pass 2: the level's nodes, the next level's work items (in slot order, so that child_base + rank finds them) and the
+// level's stretch of trisw.  The grid arithmetic is done in double: a plane that lands a rounding error (2^-52 of the
+// node's extent) inside the box it should contain is covered many times over by the walk's slack (2^-17 of the scene's extent).
+__global__ void k8_emit(uint32_t n_items, uint32_t level_base, uint32_t next_base, uint32_t tri_level_base, const DNode4* __restrict__ n4,
+                        const DTri* __restrict__ tris, const uint32_t* __restrict__ items, const uint32_t* __restrict__ scan_inner,
+                        const uint32_t* __restrict__ scan_tris, DNode8* __restrict__ out, uint32_t* __restrict__ next_items, DTri* __restrict__ trisw,
+                        uint32_t* __restrict__ shape /* per node: inner children | leaf slots << 8 */) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    W8Slot s[8];
+    const int ns = w8_gather(n4, items[i], s);
+    // what the walk culls with.  Inner child: the reference node's box.  Leaf slot: the bounds of its triangles' vertices --
+    // what a hit needs is that the slot's box holds the triangle; the slot's reference box (the gate) can be far larger:
+    // a single-triangle leaf carries its parent's box, a one-triangle scene a box of +-FLT_MAX.
+    float nlo[3] = { RT_INF, RT_INF, RT_INF }, nhi[3] = { -RT_INF, -RT_INF, -RT_INF };
+    for (int k = 0; k < ns; k++) {
+        if (w8_is_leaf(s[k].ref)) {
+            const uint32_t first = w8_leaf_first(s[k].ref), cnt = w8_leaf_count(s[k].ref);
+            for (int a = 0; a < 3; a++) { s[k].lo[a] = RT_INF; s[k].hi[a] = -RT_INF; }
+            for (uint32_t t = 0; t < cnt; t++) {
+                const DTri& tr = tris[first + t];
+                for (int a = 0; a < 3; a++) {
+                    s[k].lo[a] = fminf(s[k].lo[a], fminf(tr.v0[a], fminf(tr.v1[a], tr.v2[a])));
+                    s[k].hi[a] = fmaxf(s[k].hi[a], fmaxf(tr.v0[a], fmaxf(tr.v1[a], tr.v2[a])));
+                }
+            }
+        }
+        for (int a = 0; a < 3; a++) { nlo[a] = fminf(nlo[a], s[k].lo[a]); nhi[a] = fmaxf(nhi[a], s[k].hi[a]); }
+    }
+    // children into the slot whose octant their centre lies in: greedy assignment by the projection of (child centre -
+    // node centre) on the slot's diagonal, the largest first (first of equals: lowest child, then lowest slot)
+    int slot_of[8], child_in[8];
+    for (int k = 0; k < 8; k++) { slot_of[k] = -1; child_in[k] = -1; }
+    {
+        float c[8][3];
+        for (int k = 0; k < ns; k++)
+            for (int a = 0; a < 3; a++) c[k][a] = ((s[k].lo[a] * 0.5f) + (s[k].hi[a] * 0.5f)) - ((nlo[a] * 0.5f) + (nhi[a] * 0.5f));
+        for (int round = 0; round < ns; round++) {
+            int bk = -1, bs = -1; float best = -RT_INF;
+            for (int k = 0; k < ns; k++) {
+                if (slot_of[k] >= 0) continue;
+                for (int sl = 0; sl < 8; sl++) {
+                    if (child_in[sl] >= 0) continue;
+                    float v = ((sl & 1) ? c[k][0] : -c[k][0]) + ((sl & 2) ? c[k][1] : -c[k][1]) + ((sl & 4) ? c[k][2] : -c[k][2]);
+                    if (!(v == v)) v = 0.0f;   // inf - inf on a scene of +-FLT_MAX boxes: any slot will do
+                    if (bk < 0 || v > best) { best = v; bk = k; bs = sl; }
+                }
+            }
+            slot_of[bk] = bs; child_in[bs] = bk;
+        }
+    }
+    DNode8 q;
+    uint32_t wlo[3][2], whi[3][2], exps = 0u;
+    for (int a = 0; a < 3; a++) {
+        float org = nlo[a], top = nhi[a];
+        if (!(org <= top)) { org = 0.0f; top = 0.0f; }   // a node without children (never made)
+        const double ext = (double)top - (double)org;
+        int e = 0;
+        bool have = false;
+        if (ext > 0.0 && ext < (double)RT_INF) {
+            (void)frexp(ext / 255.0, &e);                  // ext / 255 = m * 2^e, m in [0.5, 1)
+            if (e < -126) e = -126;                         // keep the step a normal float
+            have = true;
+        } else if (ext > 0.0) { e = 127; have = true; }     // an extent beyond FLT_MAX: the largest step there is
+        for (;;) {
+            bool fits = true;
+            uint32_t l[2] = { 0u, 0u }, h[2] = { 0u, 0u };
+            const double st = ldexp(1.0, e);
+            for (int sl = 0; sl < 8; sl++) {
+                uint32_t ql = 255u, qh = 0u;                // unused slot: an inverted box (its meta byte is 0 as well)
+                const int k = child_in[sl];
+                if (k >= 0 && have) {
+                    const double fl = floor(((double)s[k].lo[a] - (double)org) / st), ce = ceil(((double)s[k].hi[a] - (double)org) / st);
+                    if (ce > 255.0 && e < 127) { fits = false; break; }
+                    ql = fl < 0.0 ? 0u : (fl > 255.0 ? 255u : (uint32_t)fl); qh = ce > 255.0 ? 255u : (ce < 0.0 ? 0u : (uint32_t)ce);
+                } else if (k >= 0) { ql = 0u; qh = 0u; }
+                l[sl >> 2] |= ql << (8 * (sl & 3)); h[sl >> 2] |= qh << (8 * (sl & 3));
+            }
+            if (fits) { wlo[a][0] = l[0]; wlo[a][1] = l[1]; whi[a][0] = h[0]; whi[a][1] = h[1]; break; }
+            e++;
+        }
+        q.org[a] = org;
+        exps |= ((uint32_t)e & 255u) << (8 * a);
+    }
+    // slots in ascending order: inner children take consecutive node numbers, leaf triangles consecutive places in trisw
+    uint32_t imask = 0u, meta[2] = { 0u, 0u }, n_inner = 0u, n_leaf = 0u, off = 0u;
+    const uint32_t child_base = next_base + scan_inner[i], tri_base = tri_level_base + scan_tris[i];
+    for (int sl = 0; sl < 8; sl++) {
+        const int k = child_in[sl];
+        if (k < 0) continue;
+        uint32_t m;
+        if (!w8_is_leaf(s[k].ref)) {
+            imask |= 1u << sl;
+            m = 0x20u | (24u + (uint32_t)sl);
+            next_items[scan_inner[i] + n_inner++] = s[k].ref;
+        } else {
+            const uint32_t first = w8_leaf_first(s[k].ref), cnt = w8_leaf_count(s[k].ref);
+            m = (((1u << cnt) - 1u) << 5) | off;
+            for (uint32_t t = 0; t < cnt; t++) {
+                DTri r = tris[first + t];
+                r.orig_id = first + t;   // the DFS rank: what the walk reports and breaks ties with
+                trisw[tri_base + off + t] = r;
+            }
+            off += cnt; n_leaf++;
+        }
+        meta[sl >> 2] |= m << (8 * (sl & 3));
+    }
+    q.exp_imask = exps | (imask << 24);
+    q.child_base = child_base; q.tri_base = tri_base; q.meta[0] = meta[0]; q.meta[1] = meta[1];
+    q.lox[0] = wlo[0][0]; q.lox[1] = wlo[0][1]; q.loy[0] = wlo[1][0]; q.loy[1] = wlo[1][1]; q.loz[0] = wlo[2][0]; q.loz[1] = wlo[2][1];
+    q.hix[0] = whi[0][0]; q.hix[1] = whi[0][1]; q.hiy[0] = whi[1][0]; q.hiy[1] = whi[1][1]; q.hiz[0] = whi[2][0]; q.hiz[1] = whi[2][1];
+    out[level_base + i] = q;
+    shape[level_base + i] = n_inner | (n_leaf << 8);
+}
+
+// Entries a walk can have waiting while it is below wide node i: the rest of the node's inner children (one entry, if there
+// are two or more) and the node's triangles (one entry, if the lane already holds postponed triangles), plus the worst of
+// what a child needs.  Levels last to first.
+__global__ void k8_stack_need(uint32_t level_base, uint32_t n_items, const DNode8* __restrict__ nodes, const uint32_t* __restrict__ shape,
+                              uint32_t* __restrict__ need) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    const uint32_t sh = shape[level_base + i], n_inner = sh & 255u, n_leaf = sh >> 8;
+    uint32_t worst = 0;
+    for (uint32_t k = 0; k < n_inner; k++) worst = max(worst, need[nodes[level_base + i].child_base + k]);
+    need[level_base + i] = (n_inner >= 2u ? 1u : 0u) + (n_leaf ? 1u : 0u) + worst;
+}
+
+// gate: per triangle, the float box of its leaf slot in nodes4 -- what rt_settle tests with upstream's expression
+__global__ void k_gate(const DNode4* __restrict__ in, uint32_t n, DGate* __restrict__ gate) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DNode4 nd = in[i];
+    for (int k = 0; k < 4; k++) {
+        const uint32_t ref = nd.child[k];
+        if (ref == RT_REF_EMPTY || !(ref & RT_REF_LEAF)) continue;
+        const uint32_t first = ref & RT_LEAF_FIRST_MASK, cnt = ((ref >> 27) & 15u) + 1u;
+        DGate g;
+        g.lo[0] = nd.lox[k]; g.lo[1] = nd.loy[k]; g.lo[2] = nd.loz[k]; g.pad0 = 0.0f;
+        g.hi[0] = nd.hix[k]; g.hi[1] = nd.hiy[k]; g.hi[2] = nd.hiz[k]; g.pad1 = 0.0f;
+        for (uint32_t t = 0; t < cnt; t++) gate[first + t] = g;
+    }
+}
+
+struct Tmp {
+    std::vector<void*> ptrs;
+    ~Tmp() { for (void* p : ptrs) (void)hipFree(p); }
+    template <class T> hipError_t alloc(T** p, size_t count) { hipError_t e = hipMalloc((void**)p, sizeof(T) * (count ? count : 1)); if (e == hipSuccess) ptrs.push_back(*p); return e; }
+};
+
+}  // namespace
+
+// Fills s->d.gate / nodes8 / trisw / n_nodes8 / walk_stack from s->d.nodes4 and s->d.tris (both already in device memory).
+int rt_build_walk_tree(rt_scene* s) {
+    HostScene& h = s->host;
+    DScene& d = s->d;
+    const uint32_t n4 = h.n_nodes4, nt = h.n_tris;
+    auto keep = [&](void** p, size_t bytes) -> int {
+        if (hipMalloc(p, bytes ? bytes : 16) != hipSuccess) { rt_set_error("rt_scene_create: out of device memory (walk tree)"); return RT_ERR_NOMEM; }
+        s->allocs.push_back(*p); s->device_bytes += bytes;
+        return RT_OK;
+    };
+    void *p_gate = nullptr, *p_trisw = nullptr, *p_nodes8 = nullptr;
+    int rc;
+    if ((rc = keep(&p_gate, sizeof(DGate) * (size_t)nt)) || (rc = keep(&p_trisw, sizeof(DTri) * (size_t)nt))) return rc;
+    d.gate = (const DGate*)p_gate; d.trisw = (const DTri*)p_trisw;
+    h.n_nodes8 = 0; h.walk_stack = 0;
+    if (!n4 || !nt) {
+        if ((rc = keep(&p_nodes8, sizeof(DNode8)))) return rc;
+        d.nodes8 = (const DNode8*)p_nodes8; d.n_nodes8 = 0; d.walk_stack = 0;
+        return RT_OK;
+    }
+    const unsigned T = 256;
+    hipLaunchKernelGGL(k_gate, dim3((n4 + T - 1) / T), dim3(T), 0, 0, d.nodes4, n4, (DGate*)p_gate);
+    RT_HIP(hipGetLastError());
+
+    Tmp tmp;
+    DNode8* wide; uint32_t *items[2], *cnt_inner, *cnt_tris, *scan_inner, *scan_tris, *shape, *need;
+    RT_HIP(tmp.alloc(&wide, n4)); RT_HIP(tmp.alloc(&items[0], n4)); RT_HIP(tmp.alloc(&items[1], n4));
+    RT_HIP(tmp.alloc(&cnt_inner, (size_t)n4 + 1)); RT_HIP(tmp.alloc(&cnt_tris, (size_t)n4 + 1));
+    RT_HIP(tmp.alloc(&scan_inner, (size_t)n4 + 1)); RT_HIP(tmp.alloc(&scan_tris, (size_t)n4 + 1));
+    RT_HIP(tmp.alloc(&shape, n4)); RT_HIP(tmp.alloc(&need, n4));
+    size_t scan_bytes = 0;
+    RT_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, cnt_inner, scan_inner, (int)n4 + 1));
+    char* scan_tmp; RT_HIP(tmp.alloc(&scan_tmp, scan_bytes));
+    RT_HIP(hipMemset(items[0], 0, sizeof(uint32_t)));   // level 0: the wide node that stands for 4-wide node 0
+    std::vector<std::pair<uint32_t, uint32_t>> level_of;   // (first node, nodes) per level
+    uint32_t level_base = 0, n_items = 1, tri_total = 0;
+    int wc = 0;
+    while (n_items > 0) {
+        if ((size_t)level_base + n_items > n4) { rt_set_error("rt_scene_create: 8-wide tree larger than the 4-wide tree"); return RT_ERR_DEVICE; }
+        hipLaunchKernelGGL(k8_count, dim3((n_items + 1 + T - 1) / T), dim3(T), 0, 0, n_items, d.nodes4, items[wc], cnt_inner, cnt_tris);
+        RT_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, cnt_inner, scan_inner, (int)n_items + 1));
+        RT_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, cnt_tris, scan_tris, (int)n_items + 1));
+        uint32_t n_next = 0, n_level_tris = 0;
+        RT_HIP(hipMemcpy(&n_next, scan_inner + n_items, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        RT_HIP(hipMemcpy(&n_level_tris, scan_tris + n_items, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const uint32_t next_base = level_base + n_items;
+        if ((size_t)next_base + n_next > n4 || (size_t)tri_total + n_level_tris > nt) { rt_set_error("rt_scene_create: 8-wide tree bookkeeping overflow"); return RT_ERR_DEVICE; }
+        hipLaunchKernelGGL(k8_emit, dim3((n_items + T - 1) / T), dim3(T), 0, 0, n_items, level_base, next_base, tri_total, d.nodes4, d.tris, items[wc],
+                           scan_inner, scan_tris, wide, items[wc ^ 1], (DTri*)p_trisw, shape);
+        RT_HIP(hipGetLastError());
+        level_of.emplace_back(level_base, n_items);
+        level_base = next_base; n_items = n_next; tri_total += n_level_tris; wc ^= 1;
+    }
+    const uint32_t n8 = level_base;
+    if (tri_total != nt) { rt_set_error("rt_scene_create: 8-wide tree does not hold every triangle exactly once"); return RT_ERR_DEVICE; }
+    if (n8 > (1u << 25)) { rt_set_error("wide BVH exceeds 2^25 nodes (32-bit node offsets)"); return RT_ERR_INVALID; }
+    for (size_t l = level_of.size(); l-- > 0;)
+        hipLaunchKernelGGL(k8_stack_need, dim3((level_of[l].second + T - 1) / T), dim3(T), 0, 0, level_of[l].first, level_of[l].second, wide, shape, need);
+    RT_HIP(hipGetLastError());
+    if ((rc = keep(&p_nodes8, sizeof(DNode8) * (size_t)n8))) return rc;
+    RT_HIP(hipMemcpy(p_nodes8, wide, sizeof(DNode8) * (size_t)n8, hipMemcpyDeviceToDevice));
+    uint32_t r_need = 0;
+    RT_HIP(hipMemcpy(&r_need, need, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    RT_HIP(hipDeviceSynchronize());
+    d.nodes8 = (const DNode8*)p_nodes8; d.n_nodes8 = n8; d.walk_stack = r_need + 2u;
+    h.n_nodes8 = n8; h.walk_stack = d.walk_stack; h.walk_levels = (uint32_t)level_of.size();
+    return RT_OK;
+}

@@ -23,6 +23,22 @@ def same_wide_nodes(h, d):
     ba, bb = a["box"].view(np.uint32), b["box"].view(np.uint32)
     zero = ((ba & 0x7FFFFFFF) == 0) & ((bb & 0x7FFFFFFF) == 0)
     assert np.array_equal(ba[~zero], bb[~zero])
+    # what the walk reads is derived from that array on the device (csrc/walk_tree.hip) and must come out the same as well;
+    # the sign of a zero plane can only move a node's origin between +0 and -0
+    (na, ga, ta), (nb, gb, tb) = h.walk_nodes(), d.walk_nodes()
+    assert len(na) == len(nb)
+    for f in na.dtype.names:
+        if f == "org":
+            oa, ob = na["org"].view(np.uint32), nb["org"].view(np.uint32)
+            z = ((oa & 0x7FFFFFFF) == 0) & ((ob & 0x7FFFFFFF) == 0)
+            assert np.array_equal(oa[~z], ob[~z])
+        else:
+            assert np.array_equal(na[f], nb[f]), f
+    assert np.array_equal(ta.view(np.uint8), tb.view(np.uint8))
+    for f in ("lo", "hi"):
+        x, y = ga[f].view(np.uint32), gb[f].view(np.uint32)
+        z = ((x & 0x7FFFFFFF) == 0) & ((y & 0x7FFFFFFF) == 0)
+        assert np.array_equal(x[~z], y[~z])
     return len(a)
 
 
@@ -37,10 +53,10 @@ def test_device_build_equals_host_build(make):
     s = make()
     h, d = both(s)
     ih, idv = h.info(), d.info()
-    for k in ("n_tris", "n_lights", "bvh2_nodes", "bvh2_depth", "bvh2_leaves", "bvh2_max_leaf", "wide_nodes", "wide_max_stack"):
+    for k in ("n_tris", "n_lights", "bvh2_nodes", "bvh2_depth", "bvh2_leaves", "bvh2_max_leaf", "wide_nodes", "wide_max_stack", "collapse_nodes", "wide_levels"):
         assert ih[k] == idv[k], k
     assert np.array_equal(h.leaf_order(), d.leaf_order())
-    assert same_wide_nodes(h, d) == ih["wide_nodes"]
+    assert same_wide_nodes(h, d) == ih["collapse_nodes"]
     rays = np.concatenate([scenes.bounce_rays(s, 100000, 5), scenes.primary_rays(s, 50000, 6) if s.cam_P is not None else scenes.bounce_rays(s, 50000, 7)])
     for mode in (0, 1):
         a, b = h.traverse(rays, mode), d.traverse(rays, mode)
@@ -51,7 +67,7 @@ def test_device_build_equals_host_build(make):
 
 
 def test_long_leaves_are_cut_the_same_way():
-    """More than RT_LEAF_MAX (4) triangles whose centroids coincide cannot be split (Geometry.h:418's axis stays -1) and end up in one leaf;
+    """More than RT_LEAF_MAX (3) triangles whose centroids coincide cannot be split (Geometry.h:418's axis stays -1) and end up in one leaf;
     the wide tree cuts such a range into a small subtree of slots.  Host and device must cut alike."""
     rng = np.random.default_rng(6)
     s = scenes.random_soup(600, seed=8)
@@ -90,11 +106,12 @@ def test_full_size_bathroom_build_and_time():
     t = time.perf_counter(); d2 = api.Scene(s, device_build=True); td2 = time.perf_counter() - t; d2.close()   # second time: no first-launch cost
     print(f"scene create: host build {th:.2f} s, device build {td:.2f} s, again {td2:.3f} s (n_tris {s.ntris})")
     ih, idv = h.info(), d.info()
-    for k in ("n_tris", "n_lights", "bvh2_nodes", "bvh2_depth", "bvh2_leaves", "bvh2_max_leaf", "wide_nodes", "wide_max_stack"):
+    for k in ("n_tris", "n_lights", "bvh2_nodes", "bvh2_depth", "bvh2_leaves", "bvh2_max_leaf", "wide_nodes", "wide_max_stack", "collapse_nodes", "wide_levels"):
         assert ih[k] == idv[k], k
     assert np.array_equal(h.leaf_order(), d.leaf_order())
-    assert same_wide_nodes(h, d) == ih["wide_nodes"]
-    assert td2 < 0.15                                      # all-device set-up (0.19 s with the host-side records and collapse of round 1)
+    assert same_wide_nodes(h, d) == ih["collapse_nodes"]
+    assert td2 < 1.0                                       # all-device set-up: 0.05 s on an idle box (0.19 s with the host-side records and collapse of round 1); generous, the box may be loaded
+    assert idv["wide_max_stack"] <= 32 and idv["wide_nodes"] < idv["collapse_nodes"]
     rays = scenes.bounce_rays(s, 1 << 20, 3)
     assert np.array_equal(h.traverse(rays).view(np.uint8), d.traverse(rays).view(np.uint8))
     h.close(); d.close()
@@ -108,38 +125,73 @@ def test_full_size_bathroom_build_and_time():
     lambda: scenes.random_soup(1, seed=2),
 ], ids=["cornell", "soup", "lattice", "bathroom", "one-triangle"])
 def test_walk_nodes_bound_what_they_stand_for(make):
-    """The 64-B nodes the kernels read (rt_scene_debug_walk_nodes) against the float tree (rt_scene_debug_wide_nodes): same
-    children; an inner child's grid box contains the reference node's box, a leaf slot's grid box contains its triangles'
-    vertices, both within one grid step; unused slots are marked in the child word; every triangle's gate box is its leaf
-    slot's box in the float tree (what upstream's rayAABB is evaluated on)."""
+    """The 80-B 8-wide nodes the kernels read (rt_scene_debug_walk_nodes) against the float tree they are derived from
+    (rt_scene_debug_wide_nodes) and the triangles: every slot's grid box contains the vertices of every triangle below it (a leaf
+    slot's within one grid step); inner children are numbered consecutively from child_base in slot order, leaf triangles
+    consecutively from tri_base; every triangle sits in exactly one leaf slot, and its record in the walk-ordered array is its
+    DFS-order record with the rank in place of orig_id; every triangle's gate box is its leaf slot's box in the float tree (what
+    upstream's rayAABB is evaluated on); the stack bound holds for the tree's shape."""
     s = make()
     sc = api.Scene(s)
     wide = sc.wide_nodes()
-    q, gate = sc.walk_nodes()
+    q, gate, trisw = sc.walk_nodes()
+    info = sc.info()
     order = sc.leaf_order()
     v = s.verts[order][:, :, :3].astype(np.float64)            # triangles in DFS leaf order
-    assert (q["child"] == wide["child"]).all()
+    # gate boxes: from the float tree's leaf slots
     EMPTY, LEAF = 0xFFFFFFFF, 0x80000000
-    org, scale = q["org"].astype(np.float64), q["scale"].astype(np.float64)
     seen = np.zeros(len(order), bool)
     for k in range(4):
-        ref = q["child"][:, k]
-        used = ref != EMPTY
-        leaf = used & ((ref & LEAF) != 0)
-        inner = used & ~leaf
-        glo = org + q["lo"][:, :, k] * scale                   # (nodes, 3)
-        ghi = org + q["hi"][:, :, k] * scale
-        flo, fhi = wide["box"][:, 0:3, k].astype(np.float64), wide["box"][:, 3:6, k].astype(np.float64)
-        assert (glo[inner] <= flo[inner]).all() and (ghi[inner] >= fhi[inner]).all()
-        step = np.maximum(scale, 0)
-        assert (flo[inner] - glo[inner] <= step[inner]).all() and (ghi[inner] - fhi[inner] <= step[inner]).all()
-        for i in np.nonzero(leaf)[0]:
+        ref = wide["child"][:, k]
+        for i in np.nonzero((ref != EMPTY) & ((ref & LEAF) != 0))[0]:
             first, cnt = int(ref[i] & 0x07FFFFFF), int((ref[i] >> 27) & 15) + 1
-            tv = v[first:first + cnt].reshape(-1, 3)
-            assert (glo[i] <= tv.min(0)).all() and (ghi[i] >= tv.max(0)).all(), (i, k)
-            assert (tv.min(0) - glo[i] <= step[i]).all() and (ghi[i] - tv.max(0) <= step[i]).all(), (i, k)
+            assert cnt <= 3
             assert (gate["lo"][first:first + cnt] == wide["box"][i, 0:3, k]).all() and (gate["hi"][first:first + cnt] == wide["box"][i, 3:6, k]).all()
             assert not seen[first:first + cnt].any()
             seen[first:first + cnt] = True
-    assert seen.all(), "a triangle without a leaf slot"
+    assert seen.all(), "a triangle without a leaf slot in the float tree"
+    # walk-ordered records
+    assert sorted(trisw["rank"].tolist()) == list(range(len(order)))
+    assert np.array_equal(trisw["v"].astype(np.float64), v[trisw["rank"]])
+    # the 8-wide tree, top down: (node, lo, hi) bounds of everything below come back up
+    n = len(q)
+    assert n == info["wide_nodes"]
+    org = q["org"].astype(np.float64)
+    step = np.ldexp(1.0, q["exp"].astype(np.int64))
+    placed = np.zeros(len(order), bool)
+    entered = np.zeros(n, bool)
+    lo_below = np.full((n, 3), np.inf); hi_below = np.full((n, 3), -np.inf)
+    need = np.zeros(n, np.int64)
+    for i in range(n - 1, -1, -1):                             # children have larger numbers than their parents (level order)
+        rank_in, off, n_inner, n_leaf, worst = 0, 0, 0, 0, 0
+        for sl in range(8):
+            m = int(q["meta"][i, sl])
+            glo = org[i] + q["lo"][i, :, sl] * step[i]; ghi = org[i] + q["hi"][i, :, sl] * step[i]
+            if m == 0:
+                assert not (q["imask"][i] >> sl) & 1
+                continue
+            if (m & 0x1F) >= 24:                               # inner child
+                assert m == (0x20 | (24 + sl)) and (q["imask"][i] >> sl) & 1
+                c = int(q["child_base"][i]) + rank_in
+                rank_in += 1; n_inner += 1
+                assert i < c < n and not entered[c]
+                entered[c] = True
+                assert (glo <= lo_below[c]).all() and (ghi >= hi_below[c]).all(), (i, sl)
+                lo_below[i] = np.minimum(lo_below[i], lo_below[c]); hi_below[i] = np.maximum(hi_below[i], hi_below[c])
+                worst = max(worst, need[c])
+            else:
+                assert not (q["imask"][i] >> sl) & 1
+                cnt = {1: 1, 3: 2, 7: 3}[m >> 5]
+                assert (m & 0x1F) == off and off + cnt <= 24
+                pos = int(q["tri_base"][i]) + off
+                off += cnt; n_leaf += 1
+                assert not placed[pos:pos + cnt].any()
+                placed[pos:pos + cnt] = True
+                tv = trisw["v"][pos:pos + cnt].astype(np.float64).reshape(-1, 3)
+                assert (glo <= tv.min(0)).all() and (ghi >= tv.max(0)).all(), (i, sl)
+                assert (tv.min(0) - glo <= step[i]).all() and (ghi - tv.max(0) <= step[i]).all(), (i, sl)
+                lo_below[i] = np.minimum(lo_below[i], tv.min(0)); hi_below[i] = np.maximum(hi_below[i], tv.max(0))
+        need[i] = (1 if n_inner >= 2 else 0) + (1 if n_leaf else 0) + worst
+    assert placed.all() and entered[1:].all() and not entered[0]
+    assert info["wide_max_stack"] == need[0] + 2
     sc.close()

@@ -334,6 +334,6 @@ def test_quantised_nodes_on_scaled_and_shifted_scenes(scale, shift):
     rays = np.concatenate([rays, scenes.primary_rays(s, 20_000, 1), axis_rays(s, 10_000)])
     assert_hits_bitexact(sc.traverse(rays, 0), o.traverse(rays, threads=8), f"scaled x{scale} +{shift}")
     assert (sc.visible(segs, 0) == o.visible(segs, threads=8)).all()
-    q, _ = sc.walk_nodes()
-    assert np.isfinite(q["scale"]).all() and (q["scale"] >= 0).all()
+    q, _, _ = sc.walk_nodes()
+    assert np.isfinite(q["org"]).all() and (q["exp"] >= -126).all()
     sc.close()

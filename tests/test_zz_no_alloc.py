@@ -23,7 +23,7 @@ def test_noalloc_entry_point_matches_the_allocating_one():
     s = scenes.interior("bathroom", 0.3, 64, 36)     # deep tree: the stacks overflow LDS into the scratch
     sc = api.Scene(s)
     info = sc.info()
-    assert info["wide_max_stack"] > 24, info
+    assert info["wide_max_stack"] > 12, info     # more entries than a lane keeps in LDS (RT_STACK_LDS)
     big = np.concatenate([scenes.primary_rays(s, 300_000, 1), scenes.bounce_rays(s, 300_000, 2)])
     small = scenes.bounce_rays(s, 70_001, 5)
     for rays in (big, small):                        # two calls in a row, the second with a smaller input

@@ -41,7 +41,7 @@ for name, rays in sets.items():
             torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
         best = min(ts)
         nodes, tris = c["nodes_visited"] / len(rays), c["tris_tested"] / len(rays)
-        bpr = 24 + 20 + 32 + nodes * 64 + tris * 64   # ray, hit, gate box; 64-B quantised nodes, 64-B triangle records
+        bpr = 24 + 20 + 32 + nodes * 80 + tris * 64   # ray, hit, gate box; 80-B quantised 8-wide nodes, 64-B triangle records
         print(f"{name:18s} closest mode{mode}: {len(rays)/best/1e6:9.1f} Mrays/s  nodes/ray {nodes:.1f} tris/ray {tris:.1f} "
               f"alg bytes/ray {bpr:.0f} -> {len(rays)*bpr/best/1e9:.0f} GB/s  exact-path rays {c['exact_path_rays']} lane occ {c['lane_busy']/max(c['lane_slots'],1):.3f} max steps/ray {c['max_steps']} (mean {(c['nodes_visited']+c['tris_tested'])/len(rays):.0f})", flush=True)
 segs = scenes.shadow_segments(s, a.n, 3)
