@@ -219,6 +219,16 @@ class OracleScene:
         return out
 
 
+def mlt_trace(seed, sample, n):
+    """What orc_mlt_render's sampler hands the chain for the first n proposals (no tracing)."""
+    out = np.zeros((n, 4), np.float32)
+    L = lib()
+    L.orc_mlt_trace.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
+    L.orc_mlt_trace.restype = None
+    L.orc_mlt_trace(seed, sample, n, out.ctypes.data)
+    return {"large": out[:, 0] < np.float32(0.3), "xy": out[:, 1:3].copy(), "accept_draw": out[:, 3].copy()}
+
+
 def rng_floats(seed, sample, pixel, stream, n):
     out = np.zeros(n, np.float32)
     lib().orc_rng_floats(seed, sample, pixel, stream, n, out.ctypes.data)
@@ -263,6 +273,8 @@ def ref():
             L.ref_vec2_index.restype = C.c_int
             L.ref_matrix_apply.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
             L.ref_tri_centre.argtypes = [C.c_void_p, C.c_void_p]
+        if hasattr(L, "ref_pss_trace"):    # round-3 probe
+            L.ref_pss_trace.argtypes = [C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
         _ref = L
     return _ref
 

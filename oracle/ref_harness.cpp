@@ -252,4 +252,32 @@ void ref_mtrandom(unsigned seed, int n, float* out) {
     for (int i = 0; i < n; i++) out[i] = r.next();
 }
 
+// PSS / PSSSampler (Sampling.h:43-139) driven by the call sequence of PSSMLTRender (Renderer.h:1013-1061): genPathC's two
+// nextPSSC() (:978-979), then per proposal `next() < largeStepProb` -> largeStep() / smallStep() (:1027-1034), genPathP's two
+// nextPSSP() (:987-988), `path_draws` calls of next() standing in for the numbers pathTrace takes from sampler->next(), and the
+// accept draw next() (:1053).  Out, 8 floats per proposal: large step?, the two nextPSSP() values, proposedState.currentIndex
+// and proposedState.pssCoords.size() before those two calls, the size after them, currentTimer, the accept draw.
+// out2 (2 floats): the two nextPSSC() values of the initial state.
+void ref_pss_trace(int proposals, int path_draws, float large_prob, float* out8, float* out2) {
+    PSSSampler sampler;
+    for (int k = 0; k < path_draws; k++) (void)sampler.next();   // getNormalization's draws come from the same next() (:998-1000)
+    out2[0] = sampler.nextPSSC();
+    out2[1] = sampler.nextPSSC();
+    for (int k = 0; k < path_draws; k++) (void)sampler.next();
+    for (int i = 0; i < proposals; i++) {
+        float* o = out8 + (size_t)i * 8;
+        const bool large = sampler.next() < large_prob;
+        if (large) sampler.largeStep(); else sampler.smallStep();
+        o[0] = large ? 1.0f : 0.0f;
+        o[3] = (float)sampler.proposedState.currentIndex;
+        o[4] = (float)sampler.proposedState.pssCoords.size();
+        o[1] = sampler.nextPSSP();
+        o[2] = sampler.nextPSSP();
+        o[5] = (float)sampler.proposedState.pssCoords.size();
+        o[6] = (float)sampler.currentTimer;
+        for (int k = 0; k < path_draws; k++) (void)sampler.next();
+        o[7] = sampler.next();
+    }
+}
+
 }  // extern "C"

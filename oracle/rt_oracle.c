@@ -1354,11 +1354,30 @@ static float mlt_acceptance(Col current, Col proposed) { /* Renderer.h:965-973 *
     float r = pl / cl;
     return (r < 1.0f) ? r : 1.0f; /* (std::min)(1.0f, r) */
 }
+/* the two primary-sample-space coordinates of path `index`: nextPSSC() / nextPSSP() always return a fresh push (pinned by
+ * tests/golden/scalars_r3.npz from the compiled Sampling.h), here the first two numbers of the path's own generator */
+static Rng mlt_coords(uint64_t seed, uint64_t sample, uint32_t index, float* u, float* v) {
+    Rng rng = rng_make(seed, sample, index, 2);
+    *u = rng_next(&rng);
+    *v = rng_next(&rng);
+    return rng;
+}
+/* test probe: what the sampler hands the chain for the first n proposals, without tracing anything: per proposal the step
+ * draw, the two coordinates and the accept draw, in the order orc_mlt_render consumes them */
+void orc_mlt_trace(uint64_t seed, uint64_t sample, int n, float* out4) {
+    Rng chain = rng_make(seed, sample, 0, 4);
+    for (int i = 0; i < n; i++) {
+        out4[i * 4 + 0] = rng_next(&chain);
+        (void)mlt_coords(seed, sample, (uint32_t)(MLT_M + 1 + i), &out4[i * 4 + 1], &out4[i * 4 + 2]);
+        out4[i * 4 + 3] = rng_next(&chain);
+    }
+}
 static Col mlt_path(Ctx* c, uint64_t seed, uint64_t sample, uint32_t index, float* x, float* y) { /* genPathC / genPathP, Renderer.h:978-992 */
     const orc_scene* s = c->s;
-    Rng rng = rng_make(seed, sample, index, 2);
-    *x = rng_next(&rng) * s->width;
-    *y = rng_next(&rng) * s->height;
+    float pu, pv;
+    Rng rng = mlt_coords(seed, sample, index, &pu, &pv);
+    *x = pu * s->width;
+    *y = pv * s->height;
     float u1 = rng_next(&rng), u2 = rng_next(&rng);
     V3 o, d;
     camera_ray(s, *x + u1, *y + u2, &o, &d); /* Renderer.h:205 */

@@ -90,6 +90,7 @@ int  orc_project(orc_scene*, const float* p3, float* xy);
  * 0 path tracing, 1 light tracing, 2 PSSMLT, 4 instant radiosity, 5 ST path tracing
  * (== 0 here: the RNG is counter based), 10 albedo AOV, 11 normal AOV, 12 direct only */
 void orc_mlt_render(orc_scene* s, int spp, uint64_t seed, uint64_t first_sample, float* film); /* PSSMLT, Renderer.h:964-1063 */
+void orc_mlt_trace(uint64_t seed, uint64_t sample, int n, float* out4); /* probe: step draw, x, y in [0,1), accept draw per proposal */
 void orc_render(orc_scene*, int mode, int spp, uint64_t seed, uint64_t first_sample,
                 float* film_rgb, int nthreads, orc_stats* stats);
 int  orc_vpl_trace(orc_scene*, int n_vpls, uint64_t seed);

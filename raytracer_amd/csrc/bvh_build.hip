@@ -321,7 +321,7 @@ __global__ void k_nodes2(uint32_t n_nodes, const GNode* __restrict__ nodes, DNod
     for (int k = 0; k < 3; k++) { o.lo[k] = s.lo[k]; o.hi[k] = s.hi[k]; }
     o.left = s.left; o.right = s.right;
     const bool leaf = s.left < 0;
-    o.first = leaf ? (int32_t)s.begin : 0; o.count = leaf ? (int32_t)s.count : 0; o.pad0 = o.pad1 = 0;
+    o.first = leaf ? (int32_t)s.begin : 0; o.count = leaf ? (int32_t)s.count : 0; o.pad0 = (int32_t)s.begin; o.pad1 = (int32_t)s.count;
     out[i] = o;
     atomicMax(stats + 0, s.depth);
     if (leaf) { atomicAdd(stats + 1, 1u); atomicMax(stats + 2, s.count); }

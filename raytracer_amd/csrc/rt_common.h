@@ -7,8 +7,8 @@
 //   trishade : 64 B / triangle (vertex normals, uvs, area), same order; only read at a hit.
 //   nodes4   : 128 B (one L2 line) per 4-wide node: SoA child boxes + child refs.  What the builders produce (host and device,
 //              byte for byte the same); every child box is the box of a reference node.  Not read by the walk.
-//   nodes8   : 80 B per 8-wide node, what the walk reads: derived on the device from nodes4 (walk_tree.hip) by opening the
-//              largest children of a 4-wide node until eight slots are taken.  Child boxes sit on a 256-step grid of the node's
+//   nodes8   : 80 B per 8-wide node, what the walk reads: derived on the device from nodes2 (walk_tree.hip) by opening the child
+//              with the largest box until eight slots are taken.  Child boxes sit on a 256-step grid of the node's
 //              own box (one byte per plane, rounded outwards), children are numbered consecutively (child_base + rank among
 //              the inner slots) and so are the node's leaf triangles (tri_base + offset in trisw), so a node needs no child
 //              references: 5 x dwordx4 per 8 children.  The traversal kernels are bound by the number of divergent load
@@ -75,7 +75,8 @@ struct DGate { float lo[3], pad0, hi[3], pad1; };   // 32 B
 struct DNode2 {      // 48 B, reference-topology node (BVHNode, Geometry.h:290): leaf <=> left < 0 && right < 0
     float lo[3]; int32_t left;
     float hi[3]; int32_t right;
-    int32_t first, count, pad0, pad1;
+    int32_t first, count;   // leaves: their triangles (DFS ranks)
+    int32_t pad0, pad1;     // every node: first DFS rank and number of the triangles below it (what walk_tree.hip builds the 8-wide tree from)
 };
 static_assert(sizeof(DTri) == 64 && sizeof(DTriShade) == 64 && sizeof(DNode4) == 128 && sizeof(DNode2) == 48 && sizeof(DNode8) == 80 && sizeof(DGate) == 32, "layout");
 

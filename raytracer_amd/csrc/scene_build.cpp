@@ -419,7 +419,7 @@ bool host_scene_build(const rt_scene_desc& d, HostScene& hs, std::string& err, D
             const BNode& s = b.nodes[i];
             DNode2& o = hs.nodes2[i];
             put3(o.lo, s.box.lo); put3(o.hi, s.box.hi);
-            o.left = s.left; o.right = s.right; o.first = (int32_t)s.first; o.count = (int32_t)s.nleaf; o.pad0 = o.pad1 = 0;
+            o.left = s.left; o.right = s.right; o.first = (int32_t)s.first; o.count = (int32_t)s.nleaf; o.pad0 = (int32_t)s.begin; o.pad1 = (int32_t)s.count;
         }
         // 4-wide tree
         if (d.n_tris > 0) {

@@ -1,19 +1,19 @@
 // walk_tree.hip — the walk's own view of the tree, derived on the device from what the builders leave there.
 //
 // The builders (scene_build.cpp on the host, bvh_build.hip on the device) produce the triangle records in DFS leaf order
-// (`tris`) and the 4-wide collapse of the reference tree with float boxes (`nodes4`), byte for byte the same.  The walk is
+// (`tris`), the reference-topology binary tree (`nodes2`) and its 4-wide collapse with float boxes (`nodes4`).  The walk is
 // only required to be conservative -- rt_settle restores upstream's candidate set per ray from the gate box of the hit it
 // reports (rt_device.h) -- so the tree it descends is built for what the traversal kernels are bound
-// by: divergent load instructions per ray.  From nodes4 this file makes
+// by, instruction issue: few, wide steps and few divergent loads per ray.  This file makes
 //   gate   : per triangle, the float box of its leaf slot in nodes4 (the reference box rt_settle tests),
-//   nodes8 : the 8-wide tree, 80 B per node (DNode8, rt_common.h), level by level: a wide node takes the children of a
-//            4-wide node and opens the one with the largest box for as long as the children fit eight slots; slots that
-//            stay free go to the single triangles of multi-triangle leaf slots; a leaf slot is bounded by its own
-//            triangles, an inner slot by its reference box; children are put into the slot whose octant (relative to
-//            the node's centre) they lie in, and numbered consecutively,
+//   nodes8 : the 8-wide tree, 80 B per node (DNode8, rt_common.h), level by level from nodes2: a wide node starts as one
+//            reference node and opens the child with the largest box, one at a time, until eight slots are taken; up to
+//            RT_LEAF_MAX triangles make a leaf slot, bounded by its own triangles; slots that stay free go to the single
+//            triangles of multi-triangle leaf slots; children are put into the slot whose octant (relative to the node's
+//            centre) they lie in, and numbered consecutively,
 //   trisw  : the triangle records in the order nodes8's leaf slots name them, DFS rank inside.
-// One implementation serves both builders, so device build == host build holds for these arrays by construction
-// (tests/test_bvh_build_gpu.py still compares them).
+// One implementation serves both builders and reads only the tree's shape, its boxes and the triangles, so device build ==
+// host build holds for these arrays by construction (tests/test_bvh_build_gpu.py still compares them).
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -28,83 +28,101 @@
 
 namespace {
 
-struct W8Slot { float lo[3], hi[3]; uint32_t ref; };   // ref as in DNode4::child: a nodes4 index, or a leaf (first rank, count)
+// A slot stands for a run of triangles in DFS rank order: everything below a reference node (bnode >= 0), or a part of a
+// long leaf (bnode < 0).  Up to RT_LEAF_MAX triangles make a leaf slot; more make a child node.
+struct W8Slot { float lo[3], hi[3]; int32_t bnode; uint32_t first, count; };
+struct W8Item { int32_t bnode; uint32_t first, count; };
 
-__device__ __forceinline__ int w8_used(const DNode4& n) {
-    int c = 0;
-    for (int k = 0; k < 4; k++) c += n.child[k] != RT_REF_EMPTY ? 1 : 0;
-    return c;
-}
-__device__ __forceinline__ W8Slot w8_child(const DNode4& n, int k) {
-    W8Slot s;
-    s.lo[0] = n.lox[k]; s.lo[1] = n.loy[k]; s.lo[2] = n.loz[k]; s.hi[0] = n.hix[k]; s.hi[1] = n.hiy[k]; s.hi[2] = n.hiz[k];
-    s.ref = n.child[k];
-    return s;
-}
 __device__ __forceinline__ float w8_area(const W8Slot& s) {
     const float sx = s.hi[0] - s.lo[0], sy = s.hi[1] - s.lo[1], sz = s.hi[2] - s.lo[2];
     return ((sx * sy) + (sy * sz) + (sx * sz)) * 2.0f;
 }
-__device__ __forceinline__ bool w8_is_leaf(uint32_t ref) { return (ref & RT_REF_LEAF) != 0u; }
-__device__ __forceinline__ uint32_t w8_leaf_first(uint32_t ref) { return ref & RT_LEAF_FIRST_MASK; }
-__device__ __forceinline__ uint32_t w8_leaf_count(uint32_t ref) { return ((ref >> 27) & 15u) + 1u; }
-__device__ __forceinline__ uint32_t w8_leaf_ref(uint32_t first, uint32_t count) { return RT_REF_LEAF | ((count - 1u) << 27) | first; }
-
-// The up to eight slots of the wide node that stands for 4-wide node `item`, in the order the 4-wide tree lists them.
-__device__ int w8_gather(const DNode4* __restrict__ n4, uint32_t item, W8Slot* s) {
-    int ns = 0;
-    {
-        const DNode4 r = n4[item];
-        for (int k = 0; k < 4; k++)
-            if (r.child[k] != RT_REF_EMPTY) s[ns++] = w8_child(r, k);
+// bounds of the vertices of triangles [first, first + count)
+__device__ inline void w8_range_box(const DTri* __restrict__ tris, uint32_t first, uint32_t count, float* lo, float* hi) {
+    for (int a = 0; a < 3; a++) { lo[a] = RT_INF; hi[a] = -RT_INF; }
+    for (uint32_t t = 0; t < count; t++) {
+        const DTri& tr = tris[first + t];
+        for (int a = 0; a < 3; a++) {
+            lo[a] = fminf(lo[a], fminf(tr.v0[a], fminf(tr.v1[a], tr.v2[a])));
+            hi[a] = fmaxf(hi[a], fmaxf(tr.v0[a], fmaxf(tr.v1[a], tr.v2[a])));
+        }
     }
-    for (;;) {   // open the inner slot with the largest box (the first of equals) among those whose children still fit
-        int pick = -1, pick_c = 0; float best = -1.0f;
+}
+// What the walk culls with.  A child node: the reference node's box (the bounds of every vertex below it; a long leaf's
+// parts: the bounds of their own triangles).  A leaf slot: the bounds of its triangles' vertices -- what a hit needs is
+// that the slot's box holds the triangle; its reference box (the gate) can be far larger: a single-triangle leaf has none
+// of its own upstream (Geometry.h:401), a one-triangle scene none at all.  BOXES = false skips what the count pass does not read.
+template <bool BOXES>
+__device__ inline W8Slot w8_slot_of_node(const DNode2* __restrict__ n2, const DTri* __restrict__ tris, int32_t node) {
+    const DNode2 c = n2[node];
+    W8Slot s; s.bnode = node; s.first = (uint32_t)c.pad0; s.count = (uint32_t)c.pad1;
+    if (s.count > RT_LEAF_MAX) { for (int a = 0; a < 3; a++) { s.lo[a] = c.lo[a]; s.hi[a] = c.hi[a]; } }
+    else if (BOXES) w8_range_box(tris, s.first, s.count, s.lo, s.hi);
+    return s;
+}
+template <bool BOXES>
+__device__ inline W8Slot w8_slot_of_range(const DTri* __restrict__ tris, uint32_t first, uint32_t count) {
+    W8Slot s; s.bnode = -1; s.first = first; s.count = count;
+    if (BOXES || count > RT_LEAF_MAX) w8_range_box(tris, first, count, s.lo, s.hi);
+    return s;
+}
+// The up to eight slots of the wide node that stands for `item`: starting from the item itself, the child node with the
+// largest box (the first of equals) is opened -- a reference node into its two children, a long leaf into two halves --
+// until eight slots are taken or only leaf slots are left; slots that are still free then go to the single triangles of
+// multi-triangle leaf slots, in slot order: every leaf slot is bounded by its own triangles, so a ray that misses one
+// triangle of a pair no longer tests it.  Slots keep the left-to-right order of the reference tree.
+template <bool BOXES>
+__device__ int w8_gather(const DNode2* __restrict__ n2, const DTri* __restrict__ tris, const W8Item& item, W8Slot* s) {
+    int ns = 1;
+    s[0].bnode = item.bnode; s[0].first = item.first; s[0].count = item.count;
+    for (int a = 0; a < 3; a++) { s[0].lo[a] = -RT_INF; s[0].hi[a] = RT_INF; }   // the item itself is always opened first
+    if (item.count <= RT_LEAF_MAX) s[0] = w8_slot_of_range<BOXES>(tris, item.first, item.count);   // a scene of 1-3 triangles
+    while (ns < 8) {
+        int pick = -1; float best = -1.0f;
         for (int i = 0; i < ns; i++) {
-            if (w8_is_leaf(s[i].ref)) continue;
-            const int c = w8_used(n4[s[i].ref]);
-            if (ns - 1 + c > 8) continue;
-            const float a = w8_area(s[i]);
-            if (a > best) { best = a; pick = i; pick_c = c; }
+            if (s[i].count <= RT_LEAF_MAX) continue;
+            float a = w8_area(s[i]);
+            if (!(a == a)) a = RT_INF;            // inf - inf: the item itself
+            if (a > best) { best = a; pick = i; }
         }
         if (pick < 0) break;
-        const DNode4 e = n4[s[pick].ref];
-        if (pick_c == 0) {   // an inner node without children does not occur; drop it rather than loop
-            for (int i = pick; i + 1 < ns; i++) s[i] = s[i + 1];
-            ns--;
-            continue;
+        const W8Slot e = s[pick];
+        W8Slot l, r;
+        bool halves = e.bnode < 0;
+        if (!halves) {
+            const DNode2 b = n2[e.bnode];
+            if (b.left >= 0 && b.right >= 0) { l = w8_slot_of_node<BOXES>(n2, tris, b.left); r = w8_slot_of_node<BOXES>(n2, tris, b.right); }
+            else halves = true;                   // a long leaf of the reference tree
         }
-        for (int i = ns - 1; i > pick; i--) s[i + pick_c - 1] = s[i];
-        int j = pick;
-        for (int k = 0; k < 4; k++)
-            if (e.child[k] != RT_REF_EMPTY) s[j++] = w8_child(e, k);
-        ns += pick_c - 1;
+        if (halves) {
+            const uint32_t h = e.count / 2u;
+            l = w8_slot_of_range<BOXES>(tris, e.first, h); r = w8_slot_of_range<BOXES>(tris, e.first + h, e.count - h);
+        }
+        for (int i = ns; i > pick + 1; i--) s[i] = s[i - 1];
+        s[pick] = l; s[pick + 1] = r; ns++;
     }
-    // slots that are still free go to the triangles of multi-triangle leaf slots, one triangle each, in slot order: every
-    // leaf slot is bounded by its own triangles, so a ray that misses one triangle of a pair no longer tests it
     for (int i = 0; i < ns && ns < 8; i++) {
-        const uint32_t ref = s[i].ref;
-        if (!w8_is_leaf(ref) || w8_leaf_count(ref) < 2u) continue;
+        if (s[i].count < 2u || s[i].count > RT_LEAF_MAX) continue;
         for (int k = ns; k > i + 1; k--) s[k] = s[k - 1];
-        s[i + 1] = s[i];
-        s[i].ref = w8_leaf_ref(w8_leaf_first(ref), 1u);
-        s[i + 1].ref = w8_leaf_ref(w8_leaf_first(ref) + 1u, w8_leaf_count(ref) - 1u);
+        const uint32_t first = s[i].first, count = s[i].count;
+        s[i] = w8_slot_of_range<BOXES>(tris, first, 1u);
+        s[i + 1] = w8_slot_of_range<BOXES>(tris, first + 1u, count - 1u);
         ns++;
     }
     return ns;
 }
 
 // pass 1 of a level: children that become wide nodes of the next level, and leaf triangles, per wide node
-__global__ void k8_count(uint32_t n_items, const DNode4* __restrict__ n4, const uint32_t* __restrict__ items, uint32_t* __restrict__ cnt_inner,
-                         uint32_t* __restrict__ cnt_tris) {
+__global__ void k8_count(uint32_t n_items, const DNode2* __restrict__ n2, const DTri* __restrict__ tris, const W8Item* __restrict__ items,
+                         uint32_t* __restrict__ cnt_inner, uint32_t* __restrict__ cnt_tris) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n_items) return;
     if (i == n_items) { cnt_inner[i] = 0u; cnt_tris[i] = 0u; return; }   // the scans' extra entry: its exclusive sum is the level's total
     W8Slot s[8];
-    const int ns = w8_gather(n4, items[i], s);
+    const int ns = w8_gather<false>(n2, tris, items[i], s);
     uint32_t ci = 0, ct = 0;
     for (int k = 0; k < ns; k++) {
-        if (w8_is_leaf(s[k].ref)) ct += w8_leaf_count(s[k].ref); else ci++;
+        if (s[k].count <= RT_LEAF_MAX) ct += s[k].count; else ci++;
     }
     cnt_inner[i] = ci; cnt_tris[i] = ct;
 }
@@ -112,32 +130,17 @@ __global__ void k8_count(uint32_t n_items, const DNode4* __restrict__ n4, const 
 // pass 2: the level's nodes, the next level's work items (in slot order, so that child_base + rank finds them) and the
 // level's stretch of trisw.  The grid arithmetic is done in double: a plane that lands a rounding error (2^-52 of the
 // node's extent) inside the box it should contain is covered many times over by the walk's slack (2^-17 of the scene's extent).
-__global__ void k8_emit(uint32_t n_items, uint32_t level_base, uint32_t next_base, uint32_t tri_level_base, const DNode4* __restrict__ n4,
-                        const DTri* __restrict__ tris, const uint32_t* __restrict__ items, const uint32_t* __restrict__ scan_inner,
-                        const uint32_t* __restrict__ scan_tris, DNode8* __restrict__ out, uint32_t* __restrict__ next_items, DTri* __restrict__ trisw,
+__global__ void k8_emit(uint32_t n_items, uint32_t level_base, uint32_t next_base, uint32_t tri_level_base, const DNode2* __restrict__ n2,
+                        const DTri* __restrict__ tris, const W8Item* __restrict__ items, const uint32_t* __restrict__ scan_inner,
+                        const uint32_t* __restrict__ scan_tris, DNode8* __restrict__ out, W8Item* __restrict__ next_items, DTri* __restrict__ trisw,
                         uint32_t* __restrict__ shape /* per node: inner children | leaf slots << 8 */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_items) return;
     W8Slot s[8];
-    const int ns = w8_gather(n4, items[i], s);
-    // what the walk culls with.  Inner child: the reference node's box.  Leaf slot: the bounds of its triangles' vertices --
-    // what a hit needs is that the slot's box holds the triangle; the slot's reference box (the gate) can be far larger:
-    // a single-triangle leaf carries its parent's box, a one-triangle scene a box of +-FLT_MAX.
+    const int ns = w8_gather<true>(n2, tris, items[i], s);
     float nlo[3] = { RT_INF, RT_INF, RT_INF }, nhi[3] = { -RT_INF, -RT_INF, -RT_INF };
-    for (int k = 0; k < ns; k++) {
-        if (w8_is_leaf(s[k].ref)) {
-            const uint32_t first = w8_leaf_first(s[k].ref), cnt = w8_leaf_count(s[k].ref);
-            for (int a = 0; a < 3; a++) { s[k].lo[a] = RT_INF; s[k].hi[a] = -RT_INF; }
-            for (uint32_t t = 0; t < cnt; t++) {
-                const DTri& tr = tris[first + t];
-                for (int a = 0; a < 3; a++) {
-                    s[k].lo[a] = fminf(s[k].lo[a], fminf(tr.v0[a], fminf(tr.v1[a], tr.v2[a])));
-                    s[k].hi[a] = fmaxf(s[k].hi[a], fmaxf(tr.v0[a], fmaxf(tr.v1[a], tr.v2[a])));
-                }
-            }
-        }
+    for (int k = 0; k < ns; k++)
         for (int a = 0; a < 3; a++) { nlo[a] = fminf(nlo[a], s[k].lo[a]); nhi[a] = fmaxf(nhi[a], s[k].hi[a]); }
-    }
     // children into the slot whose octant their centre lies in: greedy assignment by the projection of (child centre -
     // node centre) on the slot's diagonal, the largest first (first of equals: lowest child, then lowest slot)
     int slot_of[8], child_in[8];
@@ -200,12 +203,13 @@ __global__ void k8_emit(uint32_t n_items, uint32_t level_base, uint32_t next_bas
         const int k = child_in[sl];
         if (k < 0) continue;
         uint32_t m;
-        if (!w8_is_leaf(s[k].ref)) {
+        if (s[k].count > RT_LEAF_MAX) {
             imask |= 1u << sl;
             m = 0x20u | (24u + (uint32_t)sl);
-            next_items[scan_inner[i] + n_inner++] = s[k].ref;
+            W8Item it; it.bnode = s[k].bnode; it.first = s[k].first; it.count = s[k].count;
+            next_items[scan_inner[i] + n_inner++] = it;
         } else {
-            const uint32_t first = w8_leaf_first(s[k].ref), cnt = w8_leaf_count(s[k].ref);
+            const uint32_t first = s[k].first, cnt = s[k].count;
             m = (((1u << cnt) - 1u) << 5) | off;
             for (uint32_t t = 0; t < cnt; t++) {
                 DTri r = tris[first + t];
@@ -286,29 +290,33 @@ int rt_build_walk_tree(rt_scene* s) {
     RT_HIP(hipGetLastError());
 
     Tmp tmp;
-    DNode8* wide; uint32_t *items[2], *cnt_inner, *cnt_tris, *scan_inner, *scan_tris, *shape, *need;
-    RT_HIP(tmp.alloc(&wide, n4)); RT_HIP(tmp.alloc(&items[0], n4)); RT_HIP(tmp.alloc(&items[1], n4));
-    RT_HIP(tmp.alloc(&cnt_inner, (size_t)n4 + 1)); RT_HIP(tmp.alloc(&cnt_tris, (size_t)n4 + 1));
-    RT_HIP(tmp.alloc(&scan_inner, (size_t)n4 + 1)); RT_HIP(tmp.alloc(&scan_tris, (size_t)n4 + 1));
-    RT_HIP(tmp.alloc(&shape, n4)); RT_HIP(tmp.alloc(&need, n4));
+    // a wide node that is not the root holds more than RT_LEAF_MAX triangles, none of them shared with a node of its level:
+    // fewer than nt nodes per level, and (every node but the root has a parent with >= 2 slots) fewer than nt in all
+    const size_t cap = (size_t)nt + 1;
+    DNode8* wide; W8Item* items[2]; uint32_t *cnt_inner, *cnt_tris, *scan_inner, *scan_tris, *shape, *need;
+    RT_HIP(tmp.alloc(&wide, cap)); RT_HIP(tmp.alloc(&items[0], cap)); RT_HIP(tmp.alloc(&items[1], cap));
+    RT_HIP(tmp.alloc(&cnt_inner, cap + 1)); RT_HIP(tmp.alloc(&cnt_tris, cap + 1));
+    RT_HIP(tmp.alloc(&scan_inner, cap + 1)); RT_HIP(tmp.alloc(&scan_tris, cap + 1));
+    RT_HIP(tmp.alloc(&shape, cap)); RT_HIP(tmp.alloc(&need, cap));
     size_t scan_bytes = 0;
-    RT_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, cnt_inner, scan_inner, (int)n4 + 1));
+    RT_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, cnt_inner, scan_inner, (int)cap + 1));
     char* scan_tmp; RT_HIP(tmp.alloc(&scan_tmp, scan_bytes));
-    RT_HIP(hipMemset(items[0], 0, sizeof(uint32_t)));   // level 0: the wide node that stands for 4-wide node 0
+    const W8Item root{ 0, 0u, nt };   // level 0: the wide node that stands for the reference tree's root
+    RT_HIP(hipMemcpy(items[0], &root, sizeof(root), hipMemcpyHostToDevice));
     std::vector<std::pair<uint32_t, uint32_t>> level_of;   // (first node, nodes) per level
     uint32_t level_base = 0, n_items = 1, tri_total = 0;
     int wc = 0;
     while (n_items > 0) {
-        if ((size_t)level_base + n_items > n4) { rt_set_error("rt_scene_create: 8-wide tree larger than the 4-wide tree"); return RT_ERR_DEVICE; }
-        hipLaunchKernelGGL(k8_count, dim3((n_items + 1 + T - 1) / T), dim3(T), 0, 0, n_items, d.nodes4, items[wc], cnt_inner, cnt_tris);
+        if ((size_t)level_base + n_items > cap) { rt_set_error("rt_scene_create: 8-wide tree bookkeeping overflow"); return RT_ERR_DEVICE; }
+        hipLaunchKernelGGL(k8_count, dim3((n_items + 1 + T - 1) / T), dim3(T), 0, 0, n_items, d.nodes2, d.tris, items[wc], cnt_inner, cnt_tris);
         RT_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, cnt_inner, scan_inner, (int)n_items + 1));
         RT_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, cnt_tris, scan_tris, (int)n_items + 1));
         uint32_t n_next = 0, n_level_tris = 0;
         RT_HIP(hipMemcpy(&n_next, scan_inner + n_items, sizeof(uint32_t), hipMemcpyDeviceToHost));
         RT_HIP(hipMemcpy(&n_level_tris, scan_tris + n_items, sizeof(uint32_t), hipMemcpyDeviceToHost));
         const uint32_t next_base = level_base + n_items;
-        if ((size_t)next_base + n_next > n4 || (size_t)tri_total + n_level_tris > nt) { rt_set_error("rt_scene_create: 8-wide tree bookkeeping overflow"); return RT_ERR_DEVICE; }
-        hipLaunchKernelGGL(k8_emit, dim3((n_items + T - 1) / T), dim3(T), 0, 0, n_items, level_base, next_base, tri_total, d.nodes4, d.tris, items[wc],
+        if ((size_t)next_base + n_next > cap || (size_t)tri_total + n_level_tris > nt) { rt_set_error("rt_scene_create: 8-wide tree bookkeeping overflow"); return RT_ERR_DEVICE; }
+        hipLaunchKernelGGL(k8_emit, dim3((n_items + T - 1) / T), dim3(T), 0, 0, n_items, level_base, next_base, tri_total, d.nodes2, d.tris, items[wc],
                            scan_inner, scan_tris, wide, items[wc ^ 1], (DTri*)p_trisw, shape);
         RT_HIP(hipGetLastError());
         level_of.emplace_back(level_base, n_items);

@@ -128,6 +128,22 @@ def pins_r2():
     print("vec2 index values over [0,1)^2:", np.unique(vec2[:256]), "edge rows:", vec2[256:].tolist())
 
 
+def pins_r3():
+    """Round-3 pin from the compiled reference: PSS / PSSSampler (Sampling.h:43-139) driven by PSSMLTRender's call sequence
+    (oracle/ref_harness.cpp ref_pss_trace) -> tests/golden/scalars_r3.npz.   python tests/golden/make_golden.py r3"""
+    import ctypes as C
+    L = orc.ref()
+    n, path_draws = 600, 7
+    trace = np.zeros((n, 8), np.float32); init = np.zeros(2, np.float32)
+    L.ref_pss_trace(n, path_draws, C.c_float(0.3), trace.ctypes.data, init.ctypes.data)
+    mt = np.zeros(1 << 15, np.float32)      # MTRandom(1): the stream both PSS::random and PSSSampler::random start from (Sampling.h:28)
+    L.ref_mtrandom(1, len(mt), mt.ctypes.data)
+    np.savez_compressed(os.path.join(HERE, "scalars_r3.npz"), pss_trace=trace, pss_init=init, pss_path_draws=np.int32(path_draws),
+                        pss_large_prob=np.float32(0.3), mt_seed1=mt)
+    print("proposals", n, "large steps", int(trace[:, 0].sum()), "largest pssCoords", int(trace[:, 5].max()),
+          "fresh every time:", bool((trace[:, 3] == trace[:, 4]).all()))
+
+
 def survey_digest():
     """SURVEY 8(d)'s fixed Cornell ray set (3 x 2^20, seed 1) through the compiled reference: a digest of its answers, so the
     GPU test's primary pin is a committed fixture and not the untracked _ref binary.   python tests/golden/make_golden.py digest"""
@@ -150,6 +166,8 @@ def survey_digest():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "r2":
         pins_r2()
+    elif len(sys.argv) > 1 and sys.argv[1] == "r3":
+        pins_r3()
     elif len(sys.argv) > 1 and sys.argv[1] == "digest":
         survey_digest()
     else:

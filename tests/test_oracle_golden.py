@@ -1,5 +1,7 @@
 """CPU: the oracle (oracle/rt_oracle.c) against fixtures produced by the compiled reference
 (tests/golden/make_golden.py) and against the reference's own unit-test vectors (RTTest/RTTest.cpp)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -75,6 +77,57 @@ def test_oracle_vs_live_reference_build():
         for i in (0, s.ntris // 3, s.ntris - 1):
             assert (bits(o.tri_derived(i)) == bits(r.tri_derived(i))).all()
         r.close()
+
+
+def pss_stream_positions(trace):
+    """Where in PSS::random's stream (an MTRandom(1), Sampling.h:28, :47) each proposal's two nextPSSP() values come from, if they
+    are fresh pushes (PSS::next, Sampling.h:60-67) and every stored coordinate costs two draws per timer tick it is behind
+    (mutate, Sampling.h:70-82; smallStepPerturb, :85-94)."""
+    pos, timer, timers, out = 0, 0, [], []
+    for large in trace[:, 0] == 1:
+        if large:
+            timer += 1; timers = []                      # largeStep: currentTimer++, proposedState.reset() (Sampling.h:118-122)
+        else:
+            for k in range(len(timers)):                 # smallStep -> smallStepPerturb(currentTimer)
+                pos += 2 * (timer - timers[k]); timers[k] = timer
+        out.append(pos); pos += 2; timers += [0, 0]      # two fresh coordinates, pssTimer 0
+    return np.array(out)
+
+
+def test_pss_sampler_never_hands_out_a_mutated_coordinate():
+    """What the PSSMLT design on both sides rests on (DESIGN section 4 "PSSMLT", oracle/rt_oracle.c orc_mlt_render): upstream's
+    PSSSampler, driven by PSSMLTRender's own call sequence (Renderer.h:1013-1061), returns from nextPSSP() a value it has just
+    pushed from its generator -- never one of the coordinates a small step mutated -- so every proposal's film position is a
+    fresh uniform draw whatever the step kind.  Pinned by the compiled reference (Sampling.h is one of the three headers
+    oracle/_ref builds): tests/golden/scalars_r3.npz, made by `make_golden.py r3` from oracle/ref_harness.cpp ref_pss_trace."""
+    g = np.load(os.path.join(GOLDEN, "scalars_r3.npz"))
+    tr, mt = g["pss_trace"], g["mt_seed1"]
+    idx_before, size_before, size_after = tr[:, 3], tr[:, 4], tr[:, 5]
+    assert (idx_before == size_before).all()             # currentIndex is past every stored coordinate: PSS::next pushes
+    assert (size_after == size_before + 2).all()
+    large = tr[:, 0] == 1
+    assert (size_before[large] == 0).all() and (size_before[~large][1:] > 0).all() and 0.2 < large.mean() < 0.4
+    assert size_before.max() >= 20                       # runs of small steps: the mutated coordinates pile up unread
+    pos = pss_stream_positions(tr)
+    assert pos[-1] + 2 <= len(mt)
+    assert np.array_equal(bits(tr[:, 1]), bits(mt[pos])) and np.array_equal(bits(tr[:, 2]), bits(mt[pos + 1]))   # raw generator output
+    assert np.array_equal(bits(g["pss_init"]), bits(mt[:2]))                                                     # currentState likewise
+    # the step decisions and accept draws are PSSSampler::random's own stream, interleaved with pathTrace's draws
+    k = int(g["pss_path_draws"])
+    dec = 2 * k + np.arange(len(tr)) * (k + 2)
+    assert np.array_equal(large, mt[dec] < g["pss_large_prob"]) and np.array_equal(bits(tr[:, 7]), bits(mt[dec + k + 1]))
+    # the restatement consumes primary-sample-space coordinates the same way: two fresh draws per proposal from a generator
+    # that nothing else reads (stream 2, keyed by the proposal's index), decisions from another (stream 4)
+    a = orc.mlt_trace(seed=5, sample=3, n=64)
+    for i in range(64):
+        assert np.array_equal(bits(a["xy"][i]), bits(orc.rng_floats(5, 3, 101 + i, 2, 2)))
+    chain = orc.rng_floats(5, 3, 0, 4, 128)
+    assert np.array_equal(a["large"], chain[0::2] < 0.3) and np.array_equal(bits(a["accept_draw"]), bits(chain[1::2]))
+    if orc.have_ref() and hasattr(orc.ref(), "ref_pss_trace"):   # and live, when the reference is here
+        import ctypes as C
+        live = np.zeros_like(tr); init = np.zeros(2, np.float32)
+        orc.ref().ref_pss_trace(len(tr), k, C.c_float(0.3), live.ctypes.data, init.ctypes.data)
+        assert np.array_equal(bits(live), bits(tr))
 
 
 def test_oracle_pssmlt_is_deterministic_and_covers_the_film():
