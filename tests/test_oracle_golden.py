@@ -109,7 +109,12 @@ def test_pss_sampler_never_hands_out_a_mutated_coordinate():
     assert (size_before[large] == 0).all() and (size_before[~large][1:] > 0).all() and 0.2 < large.mean() < 0.4
     assert size_before.max() >= 20                       # runs of small steps: the mutated coordinates pile up unread
     pos = pss_stream_positions(tr)
-    assert pos[-1] + 2 <= len(mt)
+    # MTRandom(1) = std::mt19937(1) through uniform_real_distribution<float>(0, 1): one 32-bit output / 2^32 in float, kept below 1.
+    # The fixture pins the first 2^15 draws from the compiled reference; numpy's MT19937 continues the same stream.
+    x = np.random.RandomState(1).randint(0, 2 ** 32, size=int(pos[-1]) + 2, dtype=np.uint64).astype(np.float32) / np.float32(4294967296.0)
+    x = np.where(x >= 1, np.nextafter(np.float32(1), np.float32(0)), x).astype(np.float32)
+    assert np.array_equal(bits(x[:len(mt)]), bits(mt))
+    mt = x
     assert np.array_equal(bits(tr[:, 1]), bits(mt[pos])) and np.array_equal(bits(tr[:, 2]), bits(mt[pos + 1]))   # raw generator output
     assert np.array_equal(bits(g["pss_init"]), bits(mt[:2]))                                                     # currentState likewise
     # the step decisions and accept draws are PSSSampler::random's own stream, interleaved with pathTrace's draws
