@@ -28,7 +28,7 @@ NODE_BYTES, TRI_BYTES = 80, 64   # the walk's quantised 8-wide node (round 2: 64
 # k_extend per ray besides node/triangle fetches: ray origin + direction (32) + flags / throughput (16) + hit write (16) + queue read/write (8)
 # + the gate box of the reported hit (32)
 EXTEND_FIXED_BYTES = 104
-PMC_FILE = os.path.join("profiles", "r02_pmc.json")   # written by tools/profile_round.sh from rocprofv3 --pmc runs of this script
+PMC_FILE = os.path.join("profiles", "r03_pmc.json")   # written by tools/pmc.sh + tools/pmc_sum.py from rocprofv3 --pmc runs of this script
 
 
 def main():
@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--repeats", type=int, default=9, help="timed regions of K steps each; the line reports their median")
+    ap.add_argument("--repeats", type=int, default=0, help="timed regions of K steps each; the line reports their median (0: as many as make >= 2.5 s of timed work, at least 9)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)   # BASELINE config 4: --width 3840 --height 2160
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--glazed", action="store_true", help="PlasticBSDF on the smooth curved fixtures too (upstream's 0/0 at their silhouettes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-unshared-pass", action="store_true", help="skip the one-stream pass that measures unshared kernel durations")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` block (the other BASELINE configs, N = 1 only)")
     ap.add_argument("--cpu-spp", type=int, default=8)
     a = ap.parse_args()
 
@@ -88,7 +89,7 @@ def main():
     torch.cuda.synchronize()
     rt.bind_film(film.data_ptr())
 
-    K, Wm, R = a.steps, a.warmup, max(1, a.repeats)
+    K, Wm, R = a.steps, a.warmup, a.repeats
     seed = 1
     # this rank's share of one timed region: K spp (weak), or its slice of the K global spp (strong)
     if a.scaling == "strong":
@@ -125,7 +126,13 @@ def main():
     samples = []   # per repeat: (dt max over ranks, rays of all ranks, closest rays of this rank)
     spp_in_film = 0
     closest_total, any_total = 0, 0
-    for _ in range(R):
+    rep = 0
+    while True:
+        # repeats: as asked, or (0) until the timed regions add up to 2.5 s and there are at least 9 of them; every rank sees the
+        # same max-over-ranks times, so all leave the loop together
+        if (R > 0 and rep >= R) or (R <= 0 and rep >= 9 and sum(t for t, _ in samples) >= 2.5) or rep >= 200:
+            break
+        rep += 1
         barrier()
         t0 = time.perf_counter()
         if k_rank:
@@ -157,9 +164,17 @@ def main():
     prof = rt.profile(reset=True)
     rt.profile_enable(False)
 
+    R = len(samples)
     rates = sorted(r / t / 1e6 for t, r in samples)
     times = sorted(t for t, _ in samples)
     med_rate, med_dt = statistics.median(rates), statistics.median(times)
+
+    # which GPU each rank ran on (PCI bus id), so that the record shows N distinct devices behind an N-GPU line
+    my_dev = f"rank {rank}: cuda:{local_rank} {torch.cuda.get_device_properties(local_rank).name} pci {pci_bus_id(local_rank)}"
+    devices = [my_dev]
+    if world > 1:
+        devices = [None] * world
+        dist.all_gather_object(devices, my_dev)
 
     out = None
     if rank == 0:
@@ -221,7 +236,9 @@ def main():
                         "note": "value / ms_per_step are the median of `n` timed regions of exactly `steps` steps each"},
             "config": {
                 "workload": f"{sdata.name} procedural stand-in{' (' + ', '.join(shape['variant']) + ' variant)' if shape['variant'] else ''}, {info['n_tris']} triangles, "
-                            f"{W}x{H}, path tracing (RT_MODE_PATH), 1 spp per step, {k_rank} spp per rank and timed region, {k_global} spp per region over all ranks",
+                            f"{W}x{H}, path tracing (RT_MODE_PATH), 1 spp per step, {k_rank} spp per rank and timed region, {k_global} spp per region over all ranks; "
+                            f"materials: {material_mix(a)}",
+                "devices": devices,
                 "triangles": info["n_tris"], "width": W, "height": H, "spp_per_rank": k_rank, "spp_global": k_global,
                 "parallelism": f"sample-partition x{world}" + (", RCCL film all-reduce" if world > 1 else "") + ", 2 streams per GPU"
                                + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearse else ""),
@@ -235,8 +252,8 @@ def main():
                 "bound": "issue",
                 "bound_is": "instruction issue (VALU slots + divergent vector-memory instructions through the TA), neither HBM nor MFMA: one more dwordx4 per node step "
                             "costs +17 % of the kernel, 12 % more VALU instructions +3 %, fabric traffic is < 0.2 of the HBM peak",
-                "kernel": "k_extend<false,false,0> (closest-hit 4-wide BVH walk)",
-                # the SURVEY 8(d) figure: ALGORITHMIC bytes (every 64-B node and 64-B triangle fetch counted, cache hits included)
+                "kernel": "k_extend<false,false,0> (closest-hit walk over the 8-wide quantised tree)",
+                # the SURVEY 8(d) figure: ALGORITHMIC bytes (every 80-B node and 64-B triangle fetch counted, cache hits included)
                 # per launch / average launch duration by HIP events over the timed regions, against the HBM peak
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -248,6 +265,7 @@ def main():
                 "frac_unshared": None if achieved_unshared is None else achieved_unshared / HBM_PEAK_GBS,
                 # fabric-side bytes per launch (L2 misses: Infinity-Cache hits included) from a PMC run of this batch shape, else null
                 "traffic": traffic,
+                "traffic_source": None if traffic is None else f"constant read from {PMC_FILE} (rocprofv3 --pmc passes of this command on this batch shape, tools/pmc.sh), not measured by this run",
                 "traffic_is": "2 x FETCH_SIZE + WRITE_SIZE per k_extend launch (MI355X_MICROARCH.md: FETCH_SIZE tallies 128-B requests at 64 B on gfx950); "
                               "L2-miss traffic on the fabric, Infinity-Cache hits included - an upper bound on HBM bytes",
                 "ceilings": ceilings,
@@ -274,6 +292,8 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sdata, a.cpu_spp)
     rt.close()
+    if rank == 0 and world == 1 and not a.no_workloads and W == 1920 and H == 1080 and a.scene == "bathroom" and a.detail == 1.0 and not shape["variant"]:
+        out["workloads"] = other_workloads(api, scenes, torch, scene, sdata)
     scene.close()
     if world > 1:
         dist.barrier()
@@ -282,9 +302,76 @@ def main():
         print(json.dumps(out), flush=True)
 
 
+def pci_bus_id(index):
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, index) == 0:
+            return buf.value.decode()
+    except Exception:
+        pass
+    return "?"
+
+
+def material_mix(a):
+    mix = "diffuse / Oren-Nayar / glass / mirror"
+    if a.glazed:
+        mix += " + plastic (fixtures, blinds, shelves)"
+    if a.dielectric:
+        mix += " + rough dielectric"
+    if a.conductor:
+        mix += " + conductor"
+    if not (a.glazed and a.dielectric):
+        mix += "; plastic and the rough dielectric are opt-in (--glazed --dielectric: upstream's estimators for them yield NaN / inf samples, DESIGN.md section 6)"
+    return mix
+
+
+def other_workloads(api, scenes, torch, bath_scene, bath_data):
+    """The other BASELINE configs in the same driver-run line (N = 1): each the median of 3 short timed regions after one warm-up
+    region, with its own film's non-finite count.  Rates are (closest + any-hit rays issued) / wall time, like `value`."""
+    import numpy as np
+    res = {}
+
+    def measure(name, scene, sdata, mode, spp, regions=3, vpls=0, note=None):
+        rt = api.RayTracer(scene)
+        if vpls:
+            rt.traceVPLs(vpls, 1)
+        rt.render(mode, spp, 1, 0); rt.sync()                      # warm-up region of the timed shape
+        rt.clear(); rt.counters(reset=True)
+        rs, ts, first = [], [], spp
+        for _ in range(regions):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            rt.render(mode, spp, 1, first); rt.sync()
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            c = rt.counters(reset=True)
+            rs.append((c["closest_rays"] + c["any_rays"]) / dt / 1e6); ts.append(dt * 1e3 / spp)
+            first += spp
+        film, n = rt.film()
+        rt.close()
+        res[name] = {"mrays_per_s": statistics.median(rs), "ms_per_spp": statistics.median(ts), "mrays_per_s_min": min(rs), "mrays_per_s_max": max(rs),
+                     "spp_per_region": spp, "regions": regions, "width": sdata.width, "height": sdata.height, "triangles": sdata.ntris,
+                     "film_nonfinite_values": int((~np.isfinite(film)).sum()), "film_spp": int(n)}
+        if note:
+            res[name]["note"] = note
+
+    measure("light_tracing_1080p", bath_scene, bath_data, api.LIGHT, 16, note="BASELINE config 5: RT_MODE_LIGHT (Renderer.h:327), atomic splats")
+    measure("pssmlt_1080p", bath_scene, bath_data, api.MLT, 32, note="BASELINE config 5: RT_MODE_MLT, one chain of 100 000 proposals per spp (Renderer.h:357)")
+    measure("instant_radiosity_50vpl_1080p", bath_scene, bath_data, api.RADIOSITY, 1, vpls=50,
+            note="BASELINE config 5: RT_MODE_RADIOSITY after rt_vpl_trace(50) (the count upstream's commented-out call names, Renderer.h:68)")
+    for label, kw, note in (("bathroom_3840x2160", dict(w=3840, h=2160), "BASELINE config 4's frame on one GPU"),
+                            ("bathroom_full_mix_1080p", dict(glazed=True, dielectric=True), "SURVEY 8(d)'s full material mix: plastic + rough dielectric (upstream's NaN / inf samples included)"),
+                            ("living_room_1080p", dict(name="living-room"), "BASELINE config 3")):
+        sd = scenes.interior(kw.get("name", "bathroom"), 1.0, kw.get("w", 1920), kw.get("h", 1080), seed=1, glazed=kw.get("glazed", False), dielectric=kw.get("dielectric", False))
+        sc = api.Scene(sd)
+        measure(label, sc, sd, api.PATH, 8 if "w" in kw else 20, note=note + "; path tracing")
+        sc.close()
+    return res
+
+
 def pmc_ceilings(shape):
     """Counter-derived ceilings of k_extend from the committed PMC summary -- only when that summary was taken on this very
-    batch shape (tools/profile_round.sh records the shape); otherwise (None, None): a number measured on another shape is
+    batch shape (tools/pmc_sum.py records the shape); otherwise (None, None): a number measured on another shape is
     not this run's."""
     path = os.path.join(ROOT, PMC_FILE)
     try:

@@ -337,20 +337,11 @@ __device__ __forceinline__ float rt_ub0(uint32_t v) { return (float)(v & 255u); 
 __device__ __forceinline__ float rt_ub1(uint32_t v) { return (float)((v >> 8) & 255u); }
 __device__ __forceinline__ float rt_ub2(uint32_t v) { return (float)((v >> 16) & 255u); }
 __device__ __forceinline__ float rt_ub3(uint32_t v) { return (float)(v >> 24); }
-#ifndef RT_GROUP_KEYS
-#define RT_GROUP_KEYS 0   // measured: nodes per ray 14.4 -> 14.4 (a whole group is hardly ever stale), -2.6 % Mrays/s for the 12 instructions per node
-#endif
 template <bool ANY>
 __device__ __forceinline__ void rt_pop(Walk& w, TravStack& st) {
-    for (;;) {
-        if (w.sp == 0u) { w.cm = 0u; return; }
-        --w.sp;
-        st.get(w.sp, w.cb, w.cm);
-        if (ANY || !RT_GROUP_KEYS) return;
-        // a node group whose nearest child lies beyond the best hit found since it was pushed: none of its children can matter
-        if (rt_cur_is_nodes(w) && __uint_as_float((w.cm & 0x00FFFF00u) << 8) > w.best.t) continue;
-        return;
-    }
+    if (w.sp == 0u) { w.cm = 0u; return; }
+    --w.sp;
+    st.get(w.sp, w.cb, w.cm);
 }
 // cur after a pop: triangles move on to pend as soon as pend is free
 template <bool ANY>
@@ -381,17 +372,14 @@ __device__ __forceinline__ void rt_node_eval(const DScene& S, Walk& w, TravStack
     const float blz = __builtin_fmaf(dz, w.inv.z, -w.pad.z), bhz = __builtin_fmaf(dz, w.inv.z, w.pad.z);
     const float limit = ANY ? w.maxT : w.best.t;
     uint32_t hit = 0u;
-    float near_ = RT_INF;   // entry distance of the nearest slot that passed
     // four slots per pass: the near / far plane bytes by the ray's sign, and per slot the bits it stands for and where they go
 #define RT_SLOT(UB, SH)                                                                                                       \
     {                                                                                                                         \
         const float lo_ = fmaxf(__builtin_fmaf(UB(nx), ax, blx), fmaxf(__builtin_fmaf(UB(ny), ay, bly), __builtin_fmaf(UB(nz), az, blz))); \
         const float hi_ = fminf(__builtin_fmaf(UB(fx), ax, bhx), fminf(__builtin_fmaf(UB(fy), ay, bhy), __builtin_fmaf(UB(fz), az, bhz))); \
-        const float en_ = fmaxf(lo_, 0.0f);                                                                                   \
-        const bool pass = en_ <= fminf(hi_, limit);                                                                           \
+        const bool pass = fmaxf(lo_, 0.0f) <= fminf(hi_, limit);                                                               \
         const uint32_t b_ = ((bits >> SH) & 255u) << ((idx >> SH) & 255u);                                                    \
         hit |= pass ? b_ : 0u;                                                                                                \
-        if (!ANY && RT_GROUP_KEYS) near_ = fminf(near_, pass ? en_ : RT_INF);                                                 \
     }
 #define RT_HALF(LOX, LOY, LOZ, HIX, HIY, HIZ, META)                                                                           \
     {                                                                                                                         \
@@ -426,11 +414,7 @@ __device__ __forceinline__ void rt_node_eval(const DScene& S, Walk& w, TravStack
     }
     const uint32_t ob = w.cb;
     w.cb = x1 ? r1.x : (x2 ? r1.y : ob);
-    // bits 8-23 of a node group: the upper half of the float `near_`, i.e. a lower bound of the entry distance of every child in
-    // the group (positive floats order like their bits; cutting the mantissa rounds down).  rt_pop drops a group whose bound
-    // lies beyond the best hit by the time it comes off the stack, instead of fetching its children to find all their slots fail.
-    const uint32_t key = (!ANY && RT_GROUP_KEYS) ? ((__float_as_uint(near_) >> 8) & 0x00FFFF00u) : 0u;
-    w.cm = x1 ? (gm | key | (hw >> 24)) : (x2 ? tm : (x3 ? rem : 0u));
+    w.cm = x1 ? (gm | (hw >> 24)) : (x2 ? tm : (x3 ? rem : 0u));
     if (!(x1 || x2 || x3)) { rt_pop<ANY>(w, st); rt_settle_refs<ANY>(w, st); }
 }
 // One triangle of pend.  Returns true when an any-hit walk found its blocker.
@@ -595,13 +579,6 @@ __device__ __forceinline__ void rt_settle(const DScene& S, Walk& w, bool& visibl
 #ifndef RT_TAIL_STEAL
 #define RT_TAIL_STEAL 1
 #endif
-// Experiment (round 3), off: a second slot per lane (below).  Lane occupancy 0.70 -> 0.81 (any-hit 0.63 -> 0.72), bit-identical
-// results, but 3766 against 3917 Mrays/s at the 4 waves per SIMD its registers need (5 waves without it: 4112; with it at 5
-// waves, spilling: 2138): the retire / load / begin code, which PMC puts at ~18 % of the kernel's instructions, runs twice --
-// once for the slot, once for lanes without a walk -- and a switch block runs at every check.
-#ifndef RT_SPARE
-#define RT_SPARE 0
-#endif
 #ifndef RT_STEAL_EVERY
 #define RT_STEAL_EVERY 4
 #endif
@@ -619,121 +596,6 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
     bool busy = false, done = false, visible = true;
     uint32_t pb = 0, pe = 0;   // the wave's pool of granted items (wave-uniform)
     bool drained = false;      // wave-uniform
-#if RT_SPARE
-    // A second slot per lane, so that a lane whose walk ends does not wait for the next batched refill: it holds either a ray
-    // that is ready to be walked (a spare: origin, direction, 1/direction, maxT) or a finished item that waits to be retired
-    // (origin, direction, hit).  Retiring and loading stay batched -- they are long, and only worth running with many lanes --
-    // but they now serve the slots, while the walks go on: a lane is idle only once both its walk and its spare are used up.
-    uint32_t x_tag = 0u;        // 0 empty, 1 spare, 2 result
-    uint32_t x_item = 0u, x_rank = 0u, x_flags = 0u;   // result: bit 0 visible, bit 1 wide (the answer still has to pass rt_settle)
-    f3 x_o = mk3(0, 0, 0), x_d = mk3(0, 0, 0), x_c = mk3(0, 0, 0);   // x_c: a spare's 1/direction, a result's (t, u, v)
-    float x_maxT = 0.0f;
-    auto retire_aux = [&]() {
-        Walk r;
-        r.o = x_o; r.dir = x_d; r.inv = mk3(1.0f / x_d.x, 1.0f / x_d.y, 1.0f / x_d.z); r.maxT = x_maxT;   // the same division as Ray::init: the same bits
-        r.best.t = x_c.x; r.best.u = x_c.y; r.best.v = x_c.z; r.best.rank = x_rank; r.wide = (x_flags & 2u) != 0u;
-        bool vis = (x_flags & 1u) != 0u;
-        rt_settle<ANY, COUNT>(S, r, vis, spill2, gstride, cn, ct, c_refused);
-        job.retire(x_item, r, vis);
-        x_tag = 0u;
-    };
-    auto retire_own = [&]() { rt_settle<ANY, COUNT>(S, w, visible, spill2, gstride, cn, ct, c_refused); job.retire(item, w, visible); done = false; };
-    auto start_spare = [&](f3 so, f3 sd, f3 si, float sm, uint32_t sit) {
-        item = sit;
-        w.best.t = RT_FLT_MAX; w.best.u = 0; w.best.v = 0; w.best.rank = 0xFFFFFFFFu;
-        rt_walk_init(S, w, so, sd, si, sm);
-        busy = true; done = false; visible = true;
-        if (COUNT) c_mine = 0;
-    };
-    for (;;) {
-        {   // a lane whose walk ended parks its result and goes on with the ray that waited in its slot
-            const bool sw = done && x_tag == 1u;
-            if (__ballot(sw)) {
-                if (sw) {
-                    const f3 so = x_o, sd = x_d, si = x_c; const float sm = x_maxT; const uint32_t sit = x_item;
-                    x_o = w.o; x_d = w.dir; x_c = mk3(w.best.t, w.best.u, w.best.v); x_rank = w.best.rank; x_maxT = w.maxT;
-                    x_item = item; x_flags = (visible ? 1u : 0u) | (w.wide ? 2u : 0u); x_tag = 2u;
-                    start_spare(so, sd, si, sm, sit);
-                }
-            }
-        }
-        const unsigned long long needm = __ballot(x_tag != 1u);   // lanes without a spare
-        const uint32_t nneed = (uint32_t)__popcll(needm);
-        if (!drained && nneed >= (uint32_t)(ANY ? RT_REFILL_IDLE_ANY : RT_REFILL_IDLE)) {
-            if (x_tag == 2u) retire_aux();
-            if (done) retire_own();
-            if (pb >= pe) {
-                if (!src.next(pb, pe)) { drained = true; continue; }
-            }
-            uint32_t take = pe - pb;
-            take = take < nneed ? take : nneed;
-            const uint32_t my = (uint32_t)__popcll(needm & ((1ULL << lane) - 1ULL));
-            if (((needm >> lane) & 1ULL) && my < take) {   // its slot is empty now; a lane without a walk takes the item straight into the walk
-                const uint32_t it = pb + my;
-                f3 a, b;
-                if (job.load(it, a, b)) {
-                    if (!busy) {
-                        item = it;
-                        const bool fin = ANY ? rt_visible_begin<COUNT>(S, a, b, mode, w, visible, spill2, gstride, cn, ct, cx)
-                                             : rt_closest_begin<COUNT>(S, a, b, mode, w, spill2, gstride, cn, ct, cx);
-                        busy = !fin; done = fin;
-                        if (COUNT) c_mine = 0;
-                    } else {
-                        Walk tw;
-                        bool tv = true;
-                        const bool fin = ANY ? rt_visible_begin<COUNT>(S, a, b, mode, tw, tv, spill2, gstride, cn, ct, cx)
-                                             : rt_closest_begin<COUNT>(S, a, b, mode, tw, spill2, gstride, cn, ct, cx);
-                        x_item = it;
-                        if (fin) {   // answered without a wide walk (an untamed ray, an empty scene): a result already
-                            x_c = mk3(tw.best.t, tw.best.u, tw.best.v); x_rank = tw.best.rank; x_flags = tv ? 1u : 0u; x_tag = 2u;
-                        } else { x_o = tw.o; x_d = tw.dir; x_c = tw.inv; x_maxT = tw.maxT; x_tag = 1u; }
-                    }
-                }
-            }
-            pb += take;
-            continue;  // re-count: short grants and dead items leave slots empty
-        }
-        if (drained) {
-            // nothing left to load: results retire as they come, and the spares that busy lanes still hold go to lanes without work
-            if (x_tag == 2u) retire_aux();
-            if (done) retire_own();
-            const unsigned long long fm = __ballot(!busy && x_tag != 1u), dm = __ballot(busy && x_tag == 1u);
-            uint32_t n = (uint32_t)__popcll(fm), nd = (uint32_t)__popcll(dm);
-            n = n < nd ? n : nd;
-            if (n) {
-                const uint32_t lt_f = (uint32_t)__popcll(fm & ((1ULL << lane) - 1ULL)), lt_d = (uint32_t)__popcll(dm & ((1ULL << lane) - 1ULL));
-                const bool thief = ((fm >> lane) & 1ULL) && lt_f < n, donor = ((dm >> lane) & 1ULL) && lt_d < n;
-                uint32_t from = lane;   // a thief's donor: the lt_f-th set bit of dm
-                unsigned long long bits = dm;
-                for (uint32_t j = 0; j < n; j++) {
-                    const uint32_t l = (uint32_t)__ffsll((long long)bits) - 1u;
-                    if (thief && lt_f == j) from = l;
-                    bits &= bits - 1ULL;
-                }
-                const f3 o_ = rt_shfl_f3(x_o, from), d_ = rt_shfl_f3(x_d, from), i_ = rt_shfl_f3(x_c, from);
-                const float mt_ = rt_shfl_f(x_maxT, from);
-                const uint32_t it_ = (uint32_t)__shfl((int)x_item, (int)from);
-                if (donor) x_tag = 0u;
-                if (thief) start_spare(o_, d_, i_, mt_, it_);
-            }
-            if (__ballot(x_tag == 1u) == 0ULL) break;   // the walks that are left end in the tail below (or there are none)
-        }
-#pragma unroll
-        for (int rep_ = 0; rep_ < RT_STEPS_PER_CHECK; rep_++) {
-            if (COUNT) { c_slots++; c_busy += busy ? 1u : 0u; c_mine += busy ? 1u : 0u; c_max = c_mine > c_max ? c_mine : c_max; }
-            if (rt_vote_step<ANY, COUNT>(S, w, busy, st, cn, ct)) {
-                busy = false; done = true;
-                if (ANY) visible = !w.occluded;
-            }
-        }
-    }
-    if (!RT_TAIL_STEAL) {   // without the tail below: step what is left to the end, then retire
-        while (__ballot(busy)) {
-            if (rt_vote_step<ANY, COUNT>(S, w, busy, st, cn, ct)) { busy = false; done = true; if (ANY) visible = !w.occluded; }
-        }
-        if (done) retire_own();
-    }
-#else
     for (;;) {
         unsigned long long idle = __ballot(!busy);
         uint32_t nidle = (uint32_t)__popcll(idle);
@@ -768,7 +630,6 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
             }
         }
     }
-#endif
     if (RT_TAIL_STEAL) {
         // every lane is busy (walking) or free here: finished lanes retired above
         unsigned long long split = 0;   // lanes whose result is one part of an item (wave-uniform)

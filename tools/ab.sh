@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B harness: runs bench.py once per library build given on the command line (RT_LIB=<path>)
 for lib in "$@"; do
-  RT_LIB=$PWD/$lib timeout -k 10 300 python -u bench.py --no-cpu-baseline > /tmp/ab.json 2>/tmp/ab.err || { tail -3 /tmp/ab.err; continue; }
+  RT_LIB=$PWD/$lib timeout -k 10 300 python -u bench.py --no-cpu-baseline --no-workloads --repeats 5 > /tmp/ab.json 2>/tmp/ab.err || { tail -3 /tmp/ab.err; continue; }
   python - "$lib" <<'PY'
 import json,sys
 d=json.load(open('/tmp/ab.json'))

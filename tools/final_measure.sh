@@ -12,9 +12,9 @@ fi
 repo=$PWD
 bash tools/pmc.sh final/pmc
 # the PMC summary must be in place before the bench lines are printed: bench.py reads its ceilings from it
-cp $out/pmc/summary.json profiles/r02_pmc.json
+cp $out/pmc/summary.json profiles/r03_pmc.json
 timeout -k 10 400 python -u bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
 echo "bench done"
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $out/prof -o vm --output-format csv -- python3 $repo/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/prof.err
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $out/prof -o vm --output-format csv -- python3 $repo/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-workloads > $out/bench_under_rocprof.json 2> $out/prof.err
 echo "kernel trace done"

@@ -1,4 +1,4 @@
-"""Slot statistics of the 4-wide tree of a scene: used slots per node, triangles per leaf slot.   python tools/tree_stats.py [bathroom|living-room] [detail]"""
+"""Slot statistics of the 8-wide walk tree of a scene.   python tools/tree_stats.py [bathroom|living-room] [detail]"""
 import os, sys
 import numpy as np
 import torch  # noqa: F401
@@ -7,49 +7,33 @@ from raytracer_amd import api, scenes
 name = sys.argv[1] if len(sys.argv) > 1 else "bathroom"
 s = scenes.interior(name, float(sys.argv[2]) if len(sys.argv) > 2 else 1.0, 1920, 1080)
 sc = api.Scene(s)
-w = sc.wide_nodes()
-ref = w["child"]
-used = ref != 0xFFFFFFFF
-leaf = used & ((ref & 0x80000000) != 0)
-cnt = ((ref >> 27) & 15) + 1
-print(name, s.ntris, "triangles", len(w), "nodes; used slots per node:", np.bincount(used.sum(1), minlength=5).tolist(),
-      "; leaf slots by triangle count:", np.bincount(cnt[leaf], minlength=8).tolist(), "; leaf slots per node:", np.bincount(leaf.sum(1), minlength=5).tolist())
-full = used.sum(1) == 4
-two = (leaf & (cnt == 2))
-print("nodes with a free slot and a 2-triangle leaf:", int(((~full) & two.any(1)).sum()), "; 2-triangle leaf slots in full nodes:", int(two[full].sum()), "of", int(two.sum()))
-# depth of the wide tree: nodes are numbered level by level, parents before children
-depth = np.zeros(len(w), np.int32)
-for k in range(4):
-    pass
-inner = used & ~leaf
-order_ok = True
-for i in range(len(w)):
-    for k in range(4):
-        if inner[i, k]:
-            depth[ref[i, k]] = depth[i] + 1
-ld = np.repeat(depth[:, None], 4, 1)[leaf]
-area = 2 * ((w["box"][:, 3] - w["box"][:, 0]) * (w["box"][:, 4] - w["box"][:, 1]) + (w["box"][:, 4] - w["box"][:, 1]) * (w["box"][:, 5] - w["box"][:, 2]) + (w["box"][:, 3] - w["box"][:, 0]) * (w["box"][:, 5] - w["box"][:, 2]))
-la = area[leaf]
-print("wide tree depth: max", int(depth.max()), "mean over leaf slots", float(ld.mean()), "area-weighted", float((ld * la).sum() / la.sum()), "; log4(nodes)", np.log(len(w)) / np.log(4))
-print("leaf-slot depth histogram:", np.bincount(ld).tolist())
-root_area = area[0][used[0]].max()
-# SAH-style expected visits for a random ray: sum over inner child slots of area / root area (+1 for the root)
-print("expected node visits (sum of inner-slot areas / scene area):", 1 + float(area[inner].sum()) / float(root_area), " expected leaf-slot visits:", float(la.sum()) / float(root_area))
-# where triangle tests go for random rays: a leaf slot is entered in proportion to the area of its (tight) box, and then tests all its
-# triangles; a triangle is hit in proportion to twice its own area.  waste = tests per hit, by triangle size.
-order = sc.leaf_order()
-v = s.verts[order][:, :, :3].astype(np.float64)
-tri_area = 0.5 * np.linalg.norm(np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]), axis=1)
-tests = np.zeros(len(v)); slot_of = np.zeros(len(v), np.int64)
-for i, k in zip(*np.nonzero(leaf)):
-    r = int(ref[i, k]); first, c = r & 0x07FFFFFF, ((r >> 27) & 15) + 1
-    tv = v[first:first + c].reshape(-1, 3)
-    ext = tv.max(0) - tv.min(0)
-    a = 2 * (ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2])
-    tests[first:first + c] = a
-print("random rays: triangle tests per true hit =", tests.sum() / (2 * tri_area).sum())
-o2 = np.argsort(-tests)
-cum = np.cumsum(tests[o2]) / tests.sum()
-for frac in (0.0001, 0.001, 0.01, 0.1):
-    n = max(1, int(len(v) * frac))
-    print(f"  the {n} triangles ({frac:.2%}) with the largest slot boxes take {cum[n - 1]:.1%} of all tests; their own hit share {(2 * tri_area[o2[:n]]).sum() / (2 * tri_area).sum():.1%}")
+q, gate, trisw = sc.walk_nodes()
+meta = q["meta"].astype(np.int64)
+used = meta != 0
+inner = used & ((meta & 0x1F) >= 24)
+leaf = used & ~inner
+cnt = np.zeros_like(meta); cnt[leaf] = np.array([0, 1, 0, 2, 0, 0, 0, 3])[meta[leaf] >> 5]
+print(name, s.ntris, "triangles,", len(q), "nodes, info", {k: v for k, v in sc.info().items() if k.startswith("wide")})
+print("used slots per node:", np.bincount(used.sum(1), minlength=9).tolist(), "mean", used.sum(1).mean())
+print("inner children per node:", np.bincount(inner.sum(1), minlength=9).tolist())
+print("leaf slots per node:", np.bincount(leaf.sum(1), minlength=9).tolist())
+print("triangles per leaf slot:", np.bincount(cnt[leaf], minlength=4).tolist(), "; triangles per node (own leaf slots):", np.bincount(cnt.sum(1), minlength=25).tolist())
+only_leaf = inner.sum(1) == 0
+print("nodes without inner children:", int(only_leaf.sum()), "their used-slot histogram:", np.bincount(used[only_leaf].sum(1), minlength=9).tolist(),
+      "their triangle-count histogram:", np.bincount(cnt[only_leaf].sum(1), minlength=25).tolist())
+# expected visits for random rays ~ sum of box areas of inner slots / root area
+step = np.ldexp(1.0, q["exp"].astype(np.int64))
+ext = (q["hi"].astype(np.float64) - q["lo"].astype(np.float64)) * step[:, :, None]          # (n, 3, 8)
+area = 2 * (ext[:, 0] * ext[:, 1] + ext[:, 1] * ext[:, 2] + ext[:, 0] * ext[:, 2])
+root = area[0][used[0]].sum()
+fill = used.sum(1)
+print("area-weighted visits: inner slots", area[inner].sum() / root, "leaf slots", area[leaf].sum() / root)
+# visits weighted by the area of the node's own box (union of its slots ~ parent's inner slot): where do visited nodes sit by fill?
+node_area = np.zeros(len(q)); node_area[0] = root
+for i in range(len(q)):
+    k = 0
+    for sl in range(8):
+        if inner[i, sl]:
+            node_area[q["child_base"][i] + k] = area[i, sl]; k += 1
+w = node_area / node_area.sum()
+print("share of (area-weighted) node visits by used slots:", [round(float(w[fill == f].sum()), 3) for f in range(9)], "mean fill of a visited node", float((w * fill).sum()))
