@@ -157,8 +157,10 @@ int rt_intersect_closest_dev(rt_scene* scene, const rt_ray* d_rays, size_t n, rt
  * traversal scratch (work counter + stack overflow) comes from one static device array of ~42 MB per GPU instead of the
  * scene's own hipMalloc'ed arrays, and the call itself performs no hipMalloc / hipFree.  Limits: n <= 2^24 rays per call
  * (RT_ERR_INVALID beyond), and a scene whose stack bounds -- 2 x (wide_max_stack - 12) + the binary tree's bound -- exceed 80
- * words per lane is refused with RT_ERR_UNSUPPORTED.  Every call on a GPU shares that GPU's array: calls that overlap
- * on one GPU (two streams, two host threads) race -- run them on one stream.  The scene's device must be current. */
+ * words per lane is refused with RT_ERR_UNSUPPORTED.  Every call on a GPU shares that GPU's array: calls on one stream are
+ * ordered by the stream, a call on another stream than the previous one's is made to wait for it on the device (an event
+ * wait, no allocation); a stream under graph capture is left alone -- the graph orders what it captured, and must not be
+ * replayed while another call on that GPU is in flight.  The scene's device must be current (RT_ERR_INVALID otherwise). */
 int rt_intersect_closest_noalloc(rt_scene* scene, const rt_ray* d_rays, size_t n, rt_hit* d_out, int mode, void* stream);
 /* --- bool Scene::visible(const Vec3&, const Vec3&) (Scene.h:169), batched; out[i] = 1 if visible. */
 int rt_intersect_any(rt_scene* scene, const rt_segment* segs, size_t n, uint8_t* out, int mode);

@@ -399,7 +399,7 @@ extern "C" int rt_intersect_any_dev(rt_scene* s, const rt_segment* d_segs, size_
 // grid (RT_NA_BLOCKS blocks), a cap on the batch (RT_NA_MAX_RAYS) and on the scene's stack bounds (RT_NA_WORDS per lane).
 // `scratch` is a host-side stand-in, not a device address: host code only ever uses the per-device pointer that
 // hipGetSymbolAddress returned for it (na_scratch_ptr), taken once per device at scene creation with that device current.
-// Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race.
+// Every call on a GPU shares that GPU's array: the entry point chains calls that arrive on different streams (below).
 #define RT_NA_BLOCKS 512u
 #define RT_NA_THREADS (RT_NA_BLOCKS * RT_BLOCK)
 #define RT_NA_WORDS 80u                       // stack words per lane: (wide_max_stack - RT_STACK_LDS) + max(bvh2 stack bound, 2)
@@ -409,15 +409,20 @@ extern "C" int rt_intersect_any_dev(rt_scene* s, const rt_segment* d_segs, size_
 static __device__ __align__(256) uint32_t scratch[RT_NA_HEADER + (size_t)RT_NA_THREADS * RT_NA_WORDS];
 #define RT_NA_MAX_DEVICES 64
 static uint32_t* na_scratch_ptr[RT_NA_MAX_DEVICES];   // device address of `scratch` on each GPU (every GPU holds its own copy)
+static hipEvent_t na_event[RT_NA_MAX_DEVICES];        // recorded behind the last launch that used that GPU's array
+static hipStream_t na_last_stream[RT_NA_MAX_DEVICES];
+static bool na_busy[RT_NA_MAX_DEVICES];
 static std::mutex na_mu;
 
-// once per device, with that device current (rt_scene_create_ex calls it)
+// once per device, with that device current (rt_scene_create_ex calls it): the array's address and the event, so that the
+// entry point itself creates nothing
 static int na_scratch_setup(int device) {
     if (device < 0 || device >= RT_NA_MAX_DEVICES) return RT_OK;   // such a device simply has no no-allocation path
     std::lock_guard<std::mutex> lk(na_mu);
     if (na_scratch_ptr[device]) return RT_OK;
     uint32_t* ptr = nullptr;
     RT_HIP(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+    RT_HIP(hipEventCreateWithFlags(&na_event[device], hipEventDisableTiming));
     na_scratch_ptr[device] = ptr;
     return RT_OK;
 }
@@ -435,17 +440,39 @@ extern "C" int rt_intersect_closest_noalloc(rt_scene* s, const rt_ray* d_rays, s
     }
     uint32_t* ptr = (s->device >= 0 && s->device < RT_NA_MAX_DEVICES) ? na_scratch_ptr[s->device] : nullptr;
     if (!ptr) { rt_set_error("rt_intersect_closest_noalloc: no static scratch on this device"); return RT_ERR_UNSUPPORTED; }
+    // the scratch pointer and the scene's arrays belong to the scene's device: a launch under another current device would
+    // go there with foreign pointers
+    int cur_dev = -1;
+    RT_HIP(hipGetDevice(&cur_dev));
+    if (cur_dev != s->device) { rt_set_error("rt_intersect_closest_noalloc: the scene's device (" + std::to_string(s->device) + ") is not current (" + std::to_string(cur_dev) + ")"); return RT_ERR_INVALID; }
     if (n == 0) return RT_OK;
     hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(na_mu);
+    // Every call on a GPU shares that GPU's array.  Calls on one stream are ordered by the stream; a call on another stream
+    // than the last one's waits, on the device, for the event recorded behind that launch (no allocation either way), so
+    // overlapping calls are serialised instead of racing.  A stream under graph capture is left alone: the graph orders what
+    // it captured, and its owner must not replay it while another call on this GPU is in flight.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (!capturing && na_busy[s->device] && na_last_stream[s->device] != st) RT_HIP(hipStreamWaitEvent(st, na_event[s->device], 0));
     // the array keeps the last call's contents: the work counter must start at zero (stack slots are written before they are read)
     RT_HIP(hipMemsetAsync(ptr, 0, sizeof(unsigned long long), st));
     const uint32_t m = (uint32_t)n;
     const unsigned blocks = (unsigned)std::min<size_t>(((size_t)m + RT_BLOCK - 1) / RT_BLOCK, std::min<size_t>(RT_NA_BLOCKS, (size_t)s->persistent_blocks));
     uint32_t* spillw = s4 ? ptr + RT_NA_HEADER : nullptr;
     uint32_t* spill2 = ptr + RT_NA_HEADER + (size_t)RT_NA_THREADS * s4;
-    hipLaunchKernelGGL(k_intersect_closest<false>, dim3(blocks), dim3(RT_BLOCK), 0, st, s->d, (const float*)d_rays, m, d_out, mode,
-                       (unsigned long long*)ptr, spillw, spill2, s->d_counters);
+    if (s->count_enabled)   // counted like rt_intersect_closest_dev's rays (rt_counters_read)
+        hipLaunchKernelGGL(k_intersect_closest<true>, dim3(blocks), dim3(RT_BLOCK), 0, st, s->d, (const float*)d_rays, m, d_out, mode,
+                           (unsigned long long*)ptr, spillw, spill2, s->d_counters);
+    else
+        hipLaunchKernelGGL(k_intersect_closest<false>, dim3(blocks), dim3(RT_BLOCK), 0, st, s->d, (const float*)d_rays, m, d_out, mode,
+                           (unsigned long long*)ptr, spillw, spill2, s->d_counters);
     RT_HIP(hipGetLastError());
+    if (!capturing) {
+        RT_HIP(hipEventRecord(na_event[s->device], st));
+        na_busy[s->device] = true; na_last_stream[s->device] = st;
+    }
     return RT_OK;
 }
 

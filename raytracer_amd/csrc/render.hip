@@ -414,8 +414,8 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_OCC) void k_shade(DScene S
                 DLight light = S.lights[li];
                 float r1 = rt_rng_next(rng), r2 = rt_rng_next(rng);
                 if (light.kind == 0) {
-                    const DTri& lt = S.tris[light.tri];
-                    col3 emitted = mat_emission(S.mats[lt.mat_gsign & 0x7FFFFFFFu]);
+                    const TriRows lt = tri_rows(S.tris + light.tri);
+                    col3 emitted = mat_emission(S.mats[tri_mat_gsign(lt) & 0x7FFFFFFFu]);
                     f3 p = tri_sample_point(lt, r1, r2);
                     float pdf = 1 / S.trishade[light.tri].area;
                     f3 wi = p - sd.x;

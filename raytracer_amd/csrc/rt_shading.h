@@ -462,20 +462,47 @@ __device__ __forceinline__ f3 tri_sample_point(const DTri& t, float r1, float r2
     float gamma = 1 - (alpha + beta);
     return ((ld3(t.v0) * alpha) + (ld3(t.v1) * beta)) + (ld3(t.v2) * gamma);
 }
+// A whole 64-B record as four 16-B rows: a shade lane gathers its records with dwordx4 loads only (fetching the 12-byte
+// fields one by one is a dwordx3 / dwordx2 / dword instruction each, and every divergent load instruction costs the texture
+// path about a cycle per lane whatever it fetches: k_shade's limiter).
+struct TriRows { float4 a, b, c, e; };
+__device__ __forceinline__ TriRows tri_rows(const DTri* t) {
+    const float4* q = reinterpret_cast<const float4*>(t);
+    TriRows r; r.a = q[0]; r.b = q[1]; r.c = q[2]; r.e = q[3];
+    return r;
+}
+__device__ __forceinline__ uint32_t tri_mat_gsign(const TriRows& r) { return __float_as_uint(r.e.w); }
+__device__ __forceinline__ f3 tri_gnormal(const TriRows& r) {
+    f3 n = mk3(r.c.y, r.c.z, r.c.w);
+    return (tri_mat_gsign(r) & 0x80000000u) ? n * -1.0f : n * 1.0f;
+}
+__device__ __forceinline__ f3 tri_sample_point(const TriRows& r, float r1, float r2) {
+    float alpha = 1 - sqrtf(r1);
+    float beta = r2 * sqrtf(r1);
+    float gamma = 1 - (alpha + beta);
+    return ((mk3(r.a.x, r.a.y, r.a.z) * alpha) + (mk3(r.a.w, r.b.x, r.b.y) * beta)) + (mk3(r.b.z, r.b.w, r.c.x) * gamma);
+}
 
 // Scene::calculateShadingData (Scene.h:185-215) for a hit
 __device__ inline Shading shading_data(const DScene& S, f3 o, f3 dir, float t, float alpha, float beta, uint32_t rank) {
     Shading sd;
-    const DTri& tr = S.tris[rank];
-    const DTriShade& sh = S.trishade[rank];
+    // of the intersection record only the normal and the material word are needed: its last two rows; the shading record whole
+    const float4* tq = reinterpret_cast<const float4*>(S.tris + rank);
+    const float4 tc = tq[2], te = tq[3];
+    const float4* sq = reinterpret_cast<const float4*>(S.trishade + rank);
+    const float4 s0 = sq[0], s1 = sq[1], s2 = sq[2], s3 = sq[3];
+    const uint32_t mat_gsign = __float_as_uint(te.w);
     float gamma = 1.0f - (alpha + beta);
     sd.x = o + (dir * t);
-    sd.gN = tri_gnormal(tr);
-    f3 n = ((ld3(sh.n0) * alpha) + (ld3(sh.n1) * beta)) + (ld3(sh.n2) * gamma);
+    {
+        f3 gn = mk3(tc.y, tc.z, tc.w);
+        sd.gN = (mat_gsign & 0x80000000u) ? gn * -1.0f : gn * 1.0f;   // tri_gnormal
+    }
+    f3 n = ((mk3(s0.x, s0.y, s0.z) * alpha) + (mk3(s0.w, s1.x, s1.y) * beta)) + (mk3(s1.z, s1.w, s2.x) * gamma);
     sd.sN = norm3(n);
-    sd.tu = sh.uv[0] * alpha + sh.uv[2] * beta + sh.uv[4] * gamma;
-    sd.tv = sh.uv[1] * alpha + sh.uv[3] * beta + sh.uv[5] * gamma;
-    sd.mat = tr.mat_gsign & 0x7FFFFFFFu;
+    sd.tu = s2.y * alpha + s2.w * beta + s3.y * gamma;
+    sd.tv = s2.z * alpha + s3.x * beta + s3.z * gamma;
+    sd.mat = mat_gsign & 0x7FFFFFFFu;
     sd.wo = -dir;
     if (S.mats[sd.mat].flags & RT_MF_TWOSIDED) {
         if (dot3(sd.wo, sd.sN) < 0) sd.sN = -sd.sN;

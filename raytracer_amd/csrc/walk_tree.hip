@@ -241,19 +241,32 @@ __global__ void k8_stack_need(uint32_t level_base, uint32_t n_items, const DNode
     need[level_base + i] = (n_inner >= 2u ? 1u : 0u) + (n_leaf ? 1u : 0u) + worst;
 }
 
-// gate: per triangle, the float box of its leaf slot in nodes4 -- what rt_settle tests with upstream's expression
-__global__ void k_gate(const DNode4* __restrict__ in, uint32_t n, DGate* __restrict__ gate) {
+// gate: per triangle, the reference box whose rayAABB decides whether upstream tests that triangle at all -- the last box on
+// the way down to it that BVHNode::traverse really tests (Geometry.h:441-471): its leaf's own box, or, for a leaf of one
+// triangle, whose box upstream never initialises (Geometry.h:401: an inverted box passes every ray), the parent's; a scene
+// of one triangle has no tested box at all.  One thread per reference node, writing the gates of its leaf children.
+__global__ void k_gate(const DNode2* __restrict__ n2, uint32_t n, DGate* __restrict__ gate) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const DNode4 nd = in[i];
-    for (int k = 0; k < 4; k++) {
-        const uint32_t ref = nd.child[k];
-        if (ref == RT_REF_EMPTY || !(ref & RT_REF_LEAF)) continue;
-        const uint32_t first = ref & RT_LEAF_FIRST_MASK, cnt = ((ref >> 27) & 15u) + 1u;
-        DGate g;
-        g.lo[0] = nd.lox[k]; g.lo[1] = nd.loy[k]; g.lo[2] = nd.loz[k]; g.pad0 = 0.0f;
-        g.hi[0] = nd.hix[k]; g.hi[1] = nd.hiy[k]; g.hi[2] = nd.hiz[k]; g.pad1 = 0.0f;
-        for (uint32_t t = 0; t < cnt; t++) gate[first + t] = g;
+    const DNode2 b = n2[i];
+    const bool leaf = b.left < 0 && b.right < 0;
+    if (leaf && i != 0u) return;            // written by its parent
+    DGate own;
+    own.lo[0] = b.lo[0]; own.lo[1] = b.lo[1]; own.lo[2] = b.lo[2]; own.pad0 = 0.0f;
+    own.hi[0] = b.hi[0]; own.hi[1] = b.hi[1]; own.hi[2] = b.hi[2]; own.pad1 = 0.0f;
+    if (leaf) {                              // the root is the only node
+        if (b.count < 2) { for (int a = 0; a < 3; a++) { own.lo[a] = -RT_FLT_MAX; own.hi[a] = RT_FLT_MAX; } }
+        for (int32_t t = 0; t < b.count; t++) gate[b.first + t] = own;
+        return;
+    }
+    const int32_t kids[2] = { b.left, b.right };
+    for (int k = 0; k < 2; k++) {
+        if (kids[k] < 0) continue;
+        const DNode2 c = n2[kids[k]];
+        if (!(c.left < 0 && c.right < 0)) continue;
+        DGate g = own;
+        if (c.count >= 2) { g.lo[0] = c.lo[0]; g.lo[1] = c.lo[1]; g.lo[2] = c.lo[2]; g.hi[0] = c.hi[0]; g.hi[1] = c.hi[1]; g.hi[2] = c.hi[2]; }
+        for (int32_t t = 0; t < c.count; t++) gate[c.first + t] = g;
     }
 }
 
@@ -269,7 +282,7 @@ struct Tmp {
 int rt_build_walk_tree(rt_scene* s) {
     HostScene& h = s->host;
     DScene& d = s->d;
-    const uint32_t n4 = h.n_nodes4, nt = h.n_tris;
+    const uint32_t nn2 = h.n_nodes2, nt = h.n_tris;
     auto keep = [&](void** p, size_t bytes) -> int {
         if (hipMalloc(p, bytes ? bytes : 16) != hipSuccess) { rt_set_error("rt_scene_create: out of device memory (walk tree)"); return RT_ERR_NOMEM; }
         s->allocs.push_back(*p); s->device_bytes += bytes;
@@ -280,13 +293,13 @@ int rt_build_walk_tree(rt_scene* s) {
     if ((rc = keep(&p_gate, sizeof(DGate) * (size_t)nt)) || (rc = keep(&p_trisw, sizeof(DTri) * (size_t)nt))) return rc;
     d.gate = (const DGate*)p_gate; d.trisw = (const DTri*)p_trisw;
     h.n_nodes8 = 0; h.walk_stack = 0;
-    if (!n4 || !nt) {
+    if (!nn2 || !nt) {
         if ((rc = keep(&p_nodes8, sizeof(DNode8)))) return rc;
         d.nodes8 = (const DNode8*)p_nodes8; d.n_nodes8 = 0; d.walk_stack = 0;
         return RT_OK;
     }
     const unsigned T = 256;
-    hipLaunchKernelGGL(k_gate, dim3((n4 + T - 1) / T), dim3(T), 0, 0, d.nodes4, n4, (DGate*)p_gate);
+    hipLaunchKernelGGL(k_gate, dim3((nn2 + T - 1) / T), dim3(T), 0, 0, d.nodes2, nn2, (DGate*)p_gate);
     RT_HIP(hipGetLastError());
 
     Tmp tmp;
