@@ -89,7 +89,6 @@ typedef struct {
     uint32_t wide_nodes, wide_max_stack;                           /* the 8-wide tree the kernels walk: nodes (80 B each), and the most 8-byte stack entries a walk can have waiting */
     uint64_t device_bytes;
     float build_seconds;
-    uint32_t collapse_nodes;                                       /* the 4-wide collapse of the reference tree the builders produce (128 B per node): what the walk tree and the gate boxes are derived from */
     uint32_t wide_levels;                                          /* levels of the 8-wide tree */
 } rt_scene_info;
 
@@ -114,10 +113,10 @@ int rt_device_set(int device);
 
 /* --- Scene::init + Scene::build (Scene.h:150, :92): Triangle::init precompute, reference-topology
  * binned-SAH BVH (Geometry.h:310-438), light list (Scene.h:107-116), flatten + upload.
- * The binned-SAH build of the binary tree (BVHNode::build, Geometry.h:391-438), Triangle::init's records, the
- * reference-topology node array and the 4-wide collapse all run on the GPU, level by level; the tree, the leaf order,
- * the wide node array and every traversal result are the same as with the host build (tests/test_bvh_build_gpu.py),
- * which rt_scene_create_ex can still ask for. */
+ * The binned-SAH build of the binary tree (BVHNode::build, Geometry.h:391-438), Triangle::init's records and the
+ * reference-topology node array all run on the GPU, level by level; the tree, the leaf order, what the walk reads
+ * (derived from them on the GPU either way) and every traversal result are the same as with the host build
+ * (tests/test_bvh_build_gpu.py), which rt_scene_create_ex can still ask for. */
 int rt_scene_create(const rt_scene_desc* desc, rt_scene** out);
 #define RT_SCENE_BUILD_DEVICE 1u   /* the default of rt_scene_create */
 #define RT_SCENE_BUILD_HOST 2u     /* everything on the host (single-threaded binary tree) */
@@ -128,10 +127,11 @@ int rt_scene_set_camera(rt_scene* scene, const rt_camera* cam);
 int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
 /* DFS leaf order of the reference tree (triangle indices), for structural parity checks. */
 int rt_scene_leaf_order(const rt_scene* scene, uint32_t* out_n_tris);
-/* The 4-wide collapse of the reference tree as the builders produce it (collapse_nodes x 128 B: lox[4] loy[4] loz[4] hix[4] hiy[4] hiz[4]
- * child[4] pad[4]) as it sits in device memory, for structural checks (device-side build == host build). */
-int rt_scene_debug_wide_nodes(rt_scene* scene, void* out, size_t max_nodes);
-/* What the traversal kernels read, derived on the device from the above: the 8-wide tree (wide_nodes x 80 B: org[3], int8 exponents
+/* The reference-topology binary tree as it sits in device memory, for structural checks (bvh2_nodes x 48 B: lo[3] left hi[3] right
+ * first count subtree_first subtree_count; leaf <=> left < 0 && right < 0; a single-triangle leaf keeps the inverted box upstream
+ * never initialises, Geometry.h:401). */
+int rt_scene_debug_ref_nodes(rt_scene* scene, void* out, size_t max_nodes);
+/* What the traversal kernels read, derived on the device from that tree and the triangles: the 8-wide tree (wide_nodes x 80 B: org[3], int8 exponents
  * ex ey ez + imask, child_base, tri_base, meta[8], plane bytes lox[8] loy[8] loz[8] hix[8] hiy[8] hiz[8]; slot s's box is
  * org + byte s x 2^e, lo rounded down, hi up; csrc/rt_common.h DNode8), the per-triangle gate boxes (n_tris x 32 B: lo[3] pad hi[3] pad, in DFS
  * leaf order: the reference box whose rayAABB (Geometry.h:207) decides whether upstream tests that triangle) and the triangle records in the

@@ -30,7 +30,7 @@ class RtError(RuntimeError):
 class SceneInfo(C.Structure):
     _fields_ = [("n_tris", C.c_uint32), ("n_lights", C.c_uint32), ("bvh2_nodes", C.c_uint32), ("bvh2_depth", C.c_uint32),
                 ("bvh2_leaves", C.c_uint32), ("bvh2_max_leaf", C.c_uint32), ("wide_nodes", C.c_uint32), ("wide_max_stack", C.c_uint32),
-                ("device_bytes", C.c_uint64), ("build_seconds", C.c_float), ("collapse_nodes", C.c_uint32), ("wide_levels", C.c_uint32)]
+                ("device_bytes", C.c_uint64), ("build_seconds", C.c_float), ("wide_levels", C.c_uint32)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -62,7 +62,7 @@ SYMBOLS = [
     "rt_renderer_create", "rt_renderer_destroy", "rt_render", "rt_film_clear", "rt_film_spp", "rt_film_read", "rt_film_bind",
     "rt_film_set_spp", "rt_vpl_trace", "rt_vpl_count", "rt_render_counters", "rt_renderer_sync", "rt_film_save_hdr",
     "rt_film_tonemap", "rt_profile_enable", "rt_profile_read", "rt_debug_bsdf_sample", "rt_debug_bsdf_eval", "rt_debug_rng", "rt_matrix_invert", "rt_scene_create_ex",
-    "rt_renderer_set_filter", "rt_render_aov", "rt_intersect_closest_noalloc", "rt_renderer_set_streams", "rt_debug_env", "rt_scene_debug_wide_nodes",
+    "rt_renderer_set_filter", "rt_render_aov", "rt_intersect_closest_noalloc", "rt_renderer_set_streams", "rt_debug_env", "rt_scene_debug_ref_nodes",
     "rt_scene_debug_walk_nodes",
 ]
 
@@ -96,7 +96,7 @@ def lib():
         _sig(L, "rt_scene_set_camera", [vp, C.POINTER(Camera)])
         _sig(L, "rt_scene_get_info", [vp, C.POINTER(SceneInfo)])
         _sig(L, "rt_scene_leaf_order", [vp, vp])
-        _sig(L, "rt_scene_debug_wide_nodes", [vp, vp, sz])
+        _sig(L, "rt_scene_debug_ref_nodes", [vp, vp, sz])
         _sig(L, "rt_scene_debug_walk_nodes", [vp, vp, sz, vp, sz, vp])
         _sig(L, "rt_host_build_info", [C.POINTER(SceneDesc), vp, C.POINTER(SceneInfo)])
         _sig(L, "rt_intersect_closest", [vp, vp, sz, vp, i32])
@@ -200,11 +200,12 @@ class Scene:
         _check(self.L.rt_scene_leaf_order(self.h, o.ctypes.data), "rt_scene_leaf_order")
         return o
 
-    def wide_nodes(self):
-        """The 4-wide collapse of the reference tree from device memory: structured array of 128-B nodes."""
-        n = self.info()["collapse_nodes"]
-        out = np.zeros(n, np.dtype([("box", np.float32, (6, 4)), ("child", np.uint32, 4), ("pad", np.uint32, 4)]))
-        _check(self.L.rt_scene_debug_wide_nodes(self.h, out.ctypes.data, n), "rt_scene_debug_wide_nodes")
+    def ref_nodes(self):
+        """The reference-topology binary tree from device memory: structured array of 48-B nodes (csrc/rt_common.h DNode2)."""
+        n = self.info()["bvh2_nodes"]
+        out = np.zeros(n, np.dtype([("lo", np.float32, 3), ("left", np.int32), ("hi", np.float32, 3), ("right", np.int32), ("first", np.int32),
+                                    ("count", np.int32), ("sub_first", np.int32), ("sub_count", np.int32)]))
+        _check(self.L.rt_scene_debug_ref_nodes(self.h, out.ctypes.data, n), "rt_scene_debug_ref_nodes")
         return out
 
     def walk_nodes(self):

@@ -327,117 +327,6 @@ __global__ void k_nodes2(uint32_t n_nodes, const GNode* __restrict__ nodes, DNod
     if (leaf) { atomicAdd(stats + 1, 1u); atomicMax(stats + 2, s.count); }
 }
 
-// ---- 4-wide collapse, one level per launch: scene_build.cpp's Collapser (same slots, same greedy opening by largest box area,
-// same level-by-level numbering), one thread per wide node of the level.
-struct DSlot { float lo[3], hi[3]; int32_t bnode; uint32_t first, count; };
-struct DWork { int32_t bnode; float lo[3], hi[3]; uint32_t first, count; };
-__device__ __forceinline__ bool d_single(const GNode* nodes, int32_t i) { return nodes[i].left < 0 && nodes[i].count <= 1u; }
-__device__ __forceinline__ float d_area(const float* lo, const float* hi) {
-    float sx = hi[0] - lo[0], sy = hi[1] - lo[1], sz = hi[2] - lo[2];
-    return ((sx * sy) + (sy * sz) + (sx * sz)) * 2.0f;
-}
-__device__ inline DSlot d_make_slot(const GNode* __restrict__ nodes, int32_t child, const float* plo, const float* phi) {
-    const GNode c = nodes[child];
-    DSlot s; s.bnode = -1; s.first = c.begin; s.count = c.left < 0 ? c.count : 0u;
-    if (c.left < 0) {
-        const bool own = c.count >= 2u;
-        for (int k = 0; k < 3; k++) { s.lo[k] = own ? c.lo[k] : plo[k]; s.hi[k] = own ? c.hi[k] : phi[k]; }
-        return s;
-    }
-    for (int k = 0; k < 3; k++) { s.lo[k] = c.lo[k]; s.hi[k] = c.hi[k]; }
-    if (d_single(nodes, c.left) && d_single(nodes, c.right)) { s.first = nodes[c.left].begin; s.count = nodes[c.left].count + nodes[c.right].count; return s; }
-    s.bnode = child; s.count = 0u;
-    return s;
-}
-// scene_build.cpp's Collapser::split_leaves
-__device__ inline int d_split_leaves(DSlot* slots, int ns) {
-    for (int i = 0; i < ns && ns < 4; i++) {
-        if (slots[i].bnode >= 0 || slots[i].count < 2u || slots[i].count > RT_LEAF_MAX) continue;
-        for (int k = ns; k > i + 1; k--) slots[k] = slots[k - 1];
-        slots[i + 1] = slots[i];
-        slots[i].count = 1u; slots[i + 1].first += 1u; slots[i + 1].count -= 1u; ns++;
-    }
-    return ns;
-}
-__device__ inline int d_gather(const GNode* __restrict__ nodes, const DWork& w, DSlot* slots) {
-    int ns = 0;
-    if (w.bnode < 0) {
-        const uint32_t parts = min(4u, (w.count + RT_LEAF_MAX - 1u) / RT_LEAF_MAX);
-        for (uint32_t p = 0; p < parts; p++) {
-            const uint32_t b = (uint32_t)((unsigned long long)w.count * p / parts), e = (uint32_t)((unsigned long long)w.count * (p + 1) / parts);
-            DSlot& s = slots[ns++];
-            for (int k = 0; k < 3; k++) { s.lo[k] = w.lo[k]; s.hi[k] = w.hi[k]; }
-            s.bnode = -1; s.first = w.first + b; s.count = e - b;
-        }
-        return d_split_leaves(slots, ns);
-    }
-    const GNode b = nodes[w.bnode];
-    slots[ns++] = d_make_slot(nodes, b.left, b.lo, b.hi);
-    slots[ns++] = d_make_slot(nodes, b.right, b.lo, b.hi);
-    while (ns < 4) {
-        int pick = -1; float best = -1.0f;
-        for (int i = 0; i < ns; i++)
-            if (slots[i].bnode >= 0) { float a = d_area(slots[i].lo, slots[i].hi); if (a > best) { best = a; pick = i; } }
-        if (pick < 0) break;
-        const GNode e = nodes[slots[pick].bnode];
-        const DSlot l = d_make_slot(nodes, e.left, e.lo, e.hi), r = d_make_slot(nodes, e.right, e.lo, e.hi);
-        for (int i = ns; i > pick + 1; i--) slots[i] = slots[i - 1];
-        slots[pick] = l; slots[pick + 1] = r; ns++;
-    }
-    return d_split_leaves(slots, ns);
-}
-__device__ __forceinline__ bool d_slot_is_node(const DSlot& s) { return s.bnode >= 0 || s.count > RT_LEAF_MAX; }
-// pass 1: how many children of each wide node become wide nodes of the next level
-__global__ void k_collapse_count(uint32_t n_items, const GNode* __restrict__ nodes, const DWork* __restrict__ items, uint32_t* __restrict__ counts) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > n_items) return;
-    if (i == n_items) { counts[i] = 0u; return; }   // the scan's extra entry: its exclusive sum is the level's total
-    DSlot slots[4];
-    const int ns = d_gather(nodes, items[i], slots);
-    uint32_t c = 0;
-    for (int k = 0; k < ns; k++) c += d_slot_is_node(slots[k]) ? 1u : 0u;
-    counts[i] = c;
-}
-// pass 2: write the level's nodes (children numbered from next_base in (parent, slot) order) and the next level's work items
-__global__ void k_collapse_emit(uint32_t n_items, uint32_t level_base, uint32_t next_base, const GNode* __restrict__ nodes, const DWork* __restrict__ items,
-                                const uint32_t* __restrict__ scan, DNode4* __restrict__ out, DWork* __restrict__ next_items) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_items) return;
-    DSlot slots[4];
-    const int ns = d_gather(nodes, items[i], slots);
-    DNode4 n;
-    const float inf = __uint_as_float(0x7F800000u);   // the empty box, as scene_build.cpp's empty_node()
-    for (int k = 0; k < 4; k++) { n.child[k] = RT_REF_EMPTY; n.pad[k] = 0u; n.lox[k] = n.loy[k] = n.loz[k] = inf; n.hix[k] = n.hiy[k] = n.hiz[k] = -inf; }
-    uint32_t slot_of_next = scan[i];
-    for (int k = 0; k < ns; k++) {
-        const DSlot& s = slots[k];
-        uint32_t ref;
-        if (d_slot_is_node(s)) {
-            DWork w; w.bnode = s.bnode; w.first = s.bnode >= 0 ? 0u : s.first; w.count = s.bnode >= 0 ? 0u : s.count;
-            for (int a = 0; a < 3; a++) { w.lo[a] = s.lo[a]; w.hi[a] = s.hi[a]; }
-            next_items[slot_of_next] = w;
-            ref = next_base + slot_of_next++;
-        } else ref = RT_REF_LEAF | ((s.count - 1u) << 27) | s.first;
-        n.lox[k] = s.lo[0]; n.loy[k] = s.lo[1]; n.loz[k] = s.lo[2]; n.hix[k] = s.hi[0]; n.hiy[k] = s.hi[1]; n.hiz[k] = s.hi[2];
-        n.child[k] = ref;
-    }
-    out[level_base + i] = n;
-}
-// entries a walk can have waiting below a wide node: its other children plus the worst of what a child needs; levels last to first
-__global__ void k_stack_need(uint32_t level_base, uint32_t n_items, const DNode4* __restrict__ nodes, uint32_t* __restrict__ need) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_items) return;
-    const DNode4& n = nodes[level_base + i];
-    uint32_t used = 0, worst = 0;
-    for (int k = 0; k < 4; k++) {
-        const uint32_t ref = n.child[k];
-        if (ref == RT_REF_EMPTY) continue;
-        used++;
-        if (!(ref & RT_REF_LEAF)) worst = max(worst, need[ref]);
-    }
-    need[level_base + i] = (used ? used - 1u : 0u) + worst;
-}
-
 struct DevMem {
     std::vector<void*> ptrs;
     ~DevMem() { for (void* p : ptrs) (void)hipFree(p); }
@@ -447,8 +336,8 @@ struct DevMem {
 }  // namespace
 
 // The binary tree level by level (see the top of this file), then -- still on the device -- the triangle records in leaf
-// order, the reference-topology node array, the 4-wide collapse and its stack bound.  Only the leaf order (4 B per triangle),
-// a few counters per level and the scene statistics come back to the host.
+// order and the reference-topology node array.  Only the leaf order (4 B per triangle), a few counters per level and the
+// scene statistics come back to the host; what the walk reads is derived from these arrays by walk_tree.hip.
 int device_scene_build(const rt_scene_desc& d, HostScene& hs, DeviceGeometry& out, std::string& err_) {
     std::string& err = err_;
     const uint32_t n = d.n_tris;
@@ -507,17 +396,9 @@ int device_scene_build(const rt_scene_desc& d, HostScene& hs, DeviceGeometry& ou
     const uint32_t* order = idx[cur];
     if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "device build: %u levels, binary tree done at %.3f s\n", levels, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
 
-    // the host keeps the special case "the whole scene is one leaf slot" (root is a leaf, or two single-triangle children)
-    GNode h_root[3];
-    BB_CHECK0(hipMemcpy(&h_root[0], nodes, sizeof(GNode), hipMemcpyDeviceToHost));
-    if (h_root[0].left < 0) return 2;
-    BB_CHECK0(hipMemcpy(&h_root[1], nodes + h_root[0].left, sizeof(GNode), hipMemcpyDeviceToHost));
-    BB_CHECK0(hipMemcpy(&h_root[2], nodes + h_root[0].right, sizeof(GNode), hipMemcpyDeviceToHost));
-    if (h_root[1].left < 0 && h_root[1].count <= 1 && h_root[2].left < 0 && h_root[2].count <= 1) return 2;
-
     // records + scene bounds, reference-topology nodes + statistics
     struct Owned { void* p = nullptr; ~Owned() { if (p) (void)hipFree(p); } void* release() { void* q = p; p = nullptr; return q; } };
-    Owned o_tris, o_shade, o_nodes2, o_nodes4;
+    Owned o_tris, o_shade, o_nodes2;
     uint32_t *tri_mat, *keys;
     BB_CHECK0(mem.alloc(&tri_mat, n)); BB_CHECK0(mem.alloc(&keys, 16));
     BB_CHECK0(hipMalloc(&o_tris.p, sizeof(DTri) * (size_t)n)); BB_CHECK0(hipMalloc(&o_shade.p, sizeof(DTriShade) * (size_t)n));
@@ -529,43 +410,10 @@ int device_scene_build(const rt_scene_desc& d, HostScene& hs, DeviceGeometry& ou
     hipLaunchKernelGGL(k_nodes2, dim3((n_nodes + T - 1) / T), dim3(T), 0, 0, n_nodes, nodes, (DNode2*)o_nodes2.p, keys + 7);
     BB_CHECK0(hipGetLastError());
 
-    // 4-wide collapse, level by level; the node array is sized by the tree (never more wide nodes than binary ones)
-    DNode4* wide; DWork* items[2]; uint32_t* need;
-    const size_t wide_cap = n;   // a wide node stands for an inner binary node, of which there are at most n - 1
-    BB_CHECK0(mem.alloc(&wide, wide_cap)); BB_CHECK0(mem.alloc(&items[0], wide_cap)); BB_CHECK0(mem.alloc(&items[1], wide_cap));
-    DWork root; memset(&root, 0, sizeof(root)); root.bnode = 0;
-    for (int k = 0; k < 3; k++) { root.lo[k] = h_root[0].lo[k]; root.hi[k] = h_root[0].hi[k]; }
-    BB_CHECK0(hipMemcpy(items[0], &root, sizeof(root), hipMemcpyHostToDevice));
-    std::vector<std::pair<uint32_t, uint32_t>> level_of;   // (first node, nodes) per level
-    uint32_t level_base = 0, n_items = 1;
-    int wc = 0;
-    while (n_items > 0) {
-        if ((size_t)level_base + n_items > wide_cap) { err = "bvh_build: wide tree larger than the binary tree"; return 0; }
-        const unsigned gi = (n_items + 1 + T - 1) / T;
-        hipLaunchKernelGGL(k_collapse_count, dim3(gi), dim3(T), 0, 0, n_items, nodes, items[wc], flags);
-        BB_CHECK0(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, flags, scan, (int)n_items + 1));
-        uint32_t n_next = 0;
-        BB_CHECK0(hipMemcpy(&n_next, scan + n_items, sizeof(uint32_t), hipMemcpyDeviceToHost));
-        const uint32_t next_base = level_base + n_items;
-        if ((size_t)next_base + n_next > wide_cap) { err = "bvh_build: wide tree larger than the binary tree"; return 0; }
-        hipLaunchKernelGGL(k_collapse_emit, dim3((n_items + T - 1) / T), dim3(T), 0, 0, n_items, level_base, next_base, nodes, items[wc], scan, wide, items[wc ^ 1]);
-        BB_CHECK0(hipGetLastError());
-        level_of.emplace_back(level_base, n_items);
-        level_base = next_base; n_items = n_next; wc ^= 1;
-    }
-    const uint32_t n_wide = level_base;
-    if (n_wide > (1u << 25)) { err = "wide BVH exceeds 2^25 nodes (32-bit node offsets)"; return 0; }
-    BB_CHECK0(mem.alloc(&need, (size_t)n_wide));
-    for (size_t l = level_of.size(); l-- > 0;)
-        hipLaunchKernelGGL(k_stack_need, dim3((level_of[l].second + T - 1) / T), dim3(T), 0, 0, level_of[l].first, level_of[l].second, wide, need);
-    BB_CHECK0(hipGetLastError());
-    BB_CHECK0(hipMalloc(&o_nodes4.p, sizeof(DNode4) * (size_t)n_wide));
-    BB_CHECK0(hipMemcpy(o_nodes4.p, wide, sizeof(DNode4) * (size_t)n_wide, hipMemcpyDeviceToDevice));
-
     // what the host needs to know
-    uint32_t r_keys[16], r_need = 0;
+    uint32_t r_keys[16];
+    BB_CHECK0(hipDeviceSynchronize());
     BB_CHECK0(hipMemcpy(r_keys, keys, sizeof(r_keys), hipMemcpyDeviceToHost));
-    BB_CHECK0(hipMemcpy(&r_need, need, sizeof(uint32_t), hipMemcpyDeviceToHost));
     hs.leaf_order.resize(n);
     BB_CHECK0(hipMemcpy(hs.leaf_order.data(), order, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
     auto unkey = [](uint32_t k) { uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k; float f; memcpy(&f, &b, 4); return f; };
@@ -573,11 +421,10 @@ int device_scene_build(const rt_scene_desc& d, HostScene& hs, DeviceGeometry& ou
     memcpy(&hs.abs_max, &r_keys[6], 4);
     hs.depth2 = r_keys[7]; hs.leaves2 = r_keys[8]; hs.max_leaf2 = r_keys[9];
     hs.max_stack2 = hs.depth2 + 2;
-    hs.max_stack4 = r_need + 2;
-    hs.n_tris = n; hs.n_nodes2 = n_nodes; hs.n_nodes4 = n_wide;
+    hs.n_tris = n; hs.n_nodes2 = n_nodes;
     out.tris = (DTri*)o_tris.release(); out.trishade = (DTriShade*)o_shade.release();
-    out.nodes2 = (DNode2*)o_nodes2.release(); out.nodes4 = (DNode4*)o_nodes4.release();
-    if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "device build: %u wide nodes in %zu levels, total %.3f s\n", n_wide, level_of.size(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    out.nodes2 = (DNode2*)o_nodes2.release();
+    if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "device build: records + nodes2 done, total %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     return 1;
 #undef BB_CHECK0
 }

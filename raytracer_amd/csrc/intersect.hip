@@ -184,23 +184,22 @@ extern "C" int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_
     HostScene& h = s->host;
     DScene& d = s->d;
     if (geom.tris) {   // a device-side build leaves its arrays in device memory: they are the scene's from here on
-        for (void* p : { (void*)geom.tris, (void*)geom.trishade, (void*)geom.nodes4, (void*)geom.nodes2 }) s->allocs.push_back(p);
-        s->device_bytes += (uint64_t)h.n_tris * (sizeof(DTri) + sizeof(DTriShade)) + (uint64_t)h.n_nodes4 * sizeof(DNode4) + (uint64_t)h.n_nodes2 * sizeof(DNode2);
-        d.tris = geom.tris; d.trishade = geom.trishade; d.nodes4 = geom.nodes4; d.nodes2 = geom.nodes2;
+        for (void* p : { (void*)geom.tris, (void*)geom.trishade, (void*)geom.nodes2 }) s->allocs.push_back(p);
+        s->device_bytes += (uint64_t)h.n_tris * (sizeof(DTri) + sizeof(DTriShade)) + (uint64_t)h.n_nodes2 * sizeof(DNode2);
+        d.tris = geom.tris; d.trishade = geom.trishade; d.nodes2 = geom.nodes2;
     }
     if (!built) { rt_set_error("rt_scene_create: " + err); return fail(RT_ERR_INVALID); }
     if ((rc = na_scratch_setup(s->device))) return fail(rc);
-    if (!geom.tris && ((rc = upload(s, h.tris, &d.tris)) || (rc = upload(s, h.trishade, &d.trishade)) || (rc = upload(s, h.nodes4, &d.nodes4)) ||
-                       (rc = upload(s, h.nodes2, &d.nodes2))))
+    if (!geom.tris && ((rc = upload(s, h.tris, &d.tris)) || (rc = upload(s, h.trishade, &d.trishade)) || (rc = upload(s, h.nodes2, &d.nodes2))))
         return fail(rc);
     if ((rc = upload(s, h.mats, &d.mats)) || (rc = upload(s, h.tex, &d.tex)) || (rc = upload(s, h.texels, &d.texels)) || (rc = upload(s, h.lights, &d.lights)))
         return fail(rc);
     d.env_cond = nullptr; d.env_marg = nullptr; d.env_func_int = h.env_func_int; d.env_nu = h.env_nu; d.env_nv = h.env_nv;
     if (!h.env_cond.empty() && ((rc = upload(s, h.env_cond, &d.env_cond)) || (rc = upload(s, h.env_marg, &d.env_marg)))) return fail(rc);
     d.n_tris = h.n_tris; d.n_lights = (uint32_t)h.lights.size();
-    d.n_nodes4 = h.n_nodes4; d.n_nodes2 = h.n_nodes2;
+    d.n_nodes2 = h.n_nodes2;
     // the walk's own arrays (gate boxes, 8-wide nodes, walk-ordered triangle records), derived on the device from whichever
-    // builder made nodes4 (walk_tree.hip)
+    // builder made tris + nodes2 (walk_tree.hip)
     if ((rc = rt_build_walk_tree(s))) return fail(rc);
     d.root_ref = d.n_tris ? 0u : RT_REF_EMPTY;
     d.max_stack2 = h.max_stack2;   // d.walk_stack: set by rt_build_walk_tree
@@ -258,17 +257,17 @@ extern "C" int rt_scene_get_info(const rt_scene* s, rt_scene_info* o) {
     const HostScene& h = s->host;
     o->n_tris = h.n_tris; o->n_lights = (uint32_t)h.lights.size();
     o->bvh2_nodes = h.n_nodes2; o->bvh2_depth = h.depth2; o->bvh2_leaves = h.leaves2; o->bvh2_max_leaf = h.max_leaf2;
-    o->wide_nodes = h.n_nodes8; o->wide_max_stack = h.walk_stack; o->collapse_nodes = h.n_nodes4; o->wide_levels = h.walk_levels;
+    o->wide_nodes = h.n_nodes8; o->wide_max_stack = h.walk_stack; o->wide_levels = h.walk_levels;
     o->device_bytes = s->device_bytes; o->build_seconds = (float)h.build_seconds;
     return RT_OK;
 }
 
-// The 4-wide tree as the builders produce it (128 B per node, float boxes), copied back from device memory: lets a test compare the
-// device-side collapse with the host's, node for node.
-extern "C" int rt_scene_debug_wide_nodes(rt_scene* s, void* out, size_t max_nodes) {
-    if (!s || !out) { rt_set_error("rt_scene_debug_wide_nodes: NULL argument"); return RT_ERR_INVALID; }
-    if (max_nodes < s->host.n_nodes4) { rt_set_error("rt_scene_debug_wide_nodes: buffer too small"); return RT_ERR_INVALID; }
-    if (s->host.n_nodes4) RT_HIP(hipMemcpy(out, s->d.nodes4, (size_t)s->host.n_nodes4 * sizeof(DNode4), hipMemcpyDeviceToHost));
+// The reference-topology binary tree as the builders leave it in device memory (48 B per node: lo[3] left hi[3] right first count
+// subtree_first subtree_count): lets a test recompute the gate boxes and check the walk tree against the tree it stands for.
+extern "C" int rt_scene_debug_ref_nodes(rt_scene* s, void* out, size_t max_nodes) {
+    if (!s || !out) { rt_set_error("rt_scene_debug_ref_nodes: NULL argument"); return RT_ERR_INVALID; }
+    if (max_nodes < s->host.n_nodes2) { rt_set_error("rt_scene_debug_ref_nodes: buffer too small"); return RT_ERR_INVALID; }
+    if (s->host.n_nodes2) RT_HIP(hipMemcpy(out, s->d.nodes2, (size_t)s->host.n_nodes2 * sizeof(DNode2), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 // The tree the walk reads (80 B per 8-wide node), the per-triangle gate boxes (32 B each, DFS rank order) and the walk-ordered
@@ -297,7 +296,7 @@ extern "C" int rt_host_build_info(const rt_scene_desc* desc, uint32_t* leaf_orde
         memset(info, 0, sizeof(*info));
         info->n_tris = h.n_tris; info->n_lights = (uint32_t)h.lights.size();
         info->bvh2_nodes = h.n_nodes2; info->bvh2_depth = h.depth2; info->bvh2_leaves = h.leaves2; info->bvh2_max_leaf = h.max_leaf2;
-        info->wide_nodes = 0; info->wide_max_stack = 0; info->collapse_nodes = h.n_nodes4; info->wide_levels = 0; info->build_seconds = (float)h.build_seconds;
+        info->wide_nodes = 0; info->wide_max_stack = 0; info->wide_levels = 0; info->build_seconds = (float)h.build_seconds;
     }
     return RT_OK;
 }

@@ -5,8 +5,6 @@
 //              reference tree, so "first visited wins ties" (Geometry.h:449) becomes
 //              "lowest index wins".  One lane fetches one record as 4 x dwordx4.
 //   trishade : 64 B / triangle (vertex normals, uvs, area), same order; only read at a hit.
-//   nodes4   : 128 B (one L2 line) per 4-wide node: SoA child boxes + child refs.  What the builders produce (host and device,
-//              byte for byte the same); every child box is the box of a reference node.  Not read by the walk.
 //   nodes8   : 80 B per 8-wide node, what the walk reads: derived on the device from nodes2 (walk_tree.hip) by opening the child
 //              with the largest box until eight slots are taken.  Child boxes sit on a 256-step grid of the node's
 //              own box (one byte per plane, rounded outwards), children are numbered consecutively (child_base + rank among
@@ -24,20 +22,16 @@
 #define RT_EPSILON 0.001f   // Geometry.h:49
 #define RT_MAX_DEPTH 4      // Renderer.h:18
 
-// child reference encoding of the 4-wide tree
-#define RT_REF_EMPTY 0xFFFFFFFFu
-#define RT_REF_LEAF 0x80000000u
-// Triangles per leaf slot of the wide tree.  The reference tree's leaves hold 1-2 triangles except where a split found every
+#define RT_REF_EMPTY 0xFFFFFFFFu   // DScene::root_ref of an empty scene
+// Triangles per leaf slot of the walk tree.  The reference tree's leaves hold 1-2 triangles except where a split found every
 // centroid on one side (Geometry.h:426): on the bench scene some twenty leaves of 8-16 large triangles (walls, floor) whose
-// box nearly every ray crosses.  Longer leaves are cut into small subtrees of slots, each bounded by its own triangles:
-// 16 -> 4 took the triangle tests per ray from 9.4 to 6.6 and added one node visit (23.3 -> 24.3): +5 % Mrays/s (3, 6, 8 the same).
-// Since round 3 at most 3: the 8-wide walk nodes name a leaf slot's triangles by three mask bits (DNode8::meta).
+// box nearly every ray crosses.  Longer runs are cut into small subtrees of slots, each bounded by its own triangles.
+// At most 3: an 8-wide walk node names a leaf slot's triangles by three mask bits (DNode8::meta).
 #ifndef RT_LEAF_MAX
 #define RT_LEAF_MAX 3u
 #endif
-static_assert(RT_LEAF_MAX >= 1u && RT_LEAF_MAX <= 3u, "a leaf slot holds 1-3 triangles: DNode8::meta has three bits for them, a DNode4 child reference four");
-#define RT_LEAF_FIRST_MASK 0x07FFFFFFu
-static inline uint32_t rt_make_leaf_ref(uint32_t first, uint32_t count) { return RT_REF_LEAF | ((count - 1u) << 27) | first; }
+static_assert(RT_LEAF_MAX >= 1u && RT_LEAF_MAX <= 3u, "a leaf slot holds 1-3 triangles: DNode8::meta has three bits for them");
+#define RT_MAX_TRIS 0x07FFFFFFu    // 2^27 - 1 triangles per scene
 
 struct DTri {        // intersection record (Triangle::rayIntersect reads n, d, e1, e2, v1, v2: Geometry.h:115-128)
     float v0[3], v1[3], v2[3];
@@ -51,11 +45,6 @@ struct DTriShade {   // shading record (Triangle::interpolateAttributes / sample
     float n0[3], n1[3], n2[3];
     float uv[6];
     float area;
-};
-struct DNode4 {      // 128 B
-    float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
-    uint32_t child[4];
-    uint32_t pad[4];
 };
 // 80 B, five 16-B rows.  Slot s's box is org + q * 2^e per axis, q = byte s of the two plane words (lo rounded down, hi up).
 // meta byte of slot s: 0 = unused; inner child: 0x20 | (24 + s); leaf: (unary triangle count 1 / 3 / 7) << 5 | offset, the
@@ -78,7 +67,7 @@ struct DNode2 {      // 48 B, reference-topology node (BVHNode, Geometry.h:290):
     int32_t first, count;   // leaves: their triangles (DFS ranks)
     int32_t pad0, pad1;     // every node: first DFS rank and number of the triangles below it (what walk_tree.hip builds the 8-wide tree from)
 };
-static_assert(sizeof(DTri) == 64 && sizeof(DTriShade) == 64 && sizeof(DNode4) == 128 && sizeof(DNode2) == 48 && sizeof(DNode8) == 80 && sizeof(DGate) == 32, "layout");
+static_assert(sizeof(DTri) == 64 && sizeof(DTriShade) == 64 && sizeof(DNode2) == 48 && sizeof(DNode8) == 80 && sizeof(DGate) == 32, "layout");
 
 struct DMaterial {   // 80 B
     uint32_t type;       // RT_MAT_*
@@ -112,7 +101,6 @@ struct DCamera {     // Camera (Scene.h:14-45)
 struct DScene {
     const DTri* tris;
     const DTriShade* trishade;
-    const DNode4* nodes4;
     const DNode8* nodes8;
     const DTri* trisw;
     const DGate* gate;
@@ -121,7 +109,7 @@ struct DScene {
     const DTexture* tex;
     const float* texels;
     const DLight* lights;
-    uint32_t n_tris, n_lights, n_nodes4, n_nodes2, n_nodes8;
+    uint32_t n_tris, n_lights, n_nodes2, n_nodes8;
     uint32_t root_ref;        // RT_REF_EMPTY for an empty scene, else node 0
     uint32_t walk_stack, max_stack2;   // most 8-byte entries a walk over nodes8 can have waiting; most words of the reference-order walk
     float abs_max;            // max |coordinate| over the scene, scales the conservative cull pad

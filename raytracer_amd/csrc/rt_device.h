@@ -332,7 +332,13 @@ __device__ __forceinline__ void rt_walk_init(const DScene& S, Walk& w, f3 o, f3 
     w.cb = 0u; w.cm = 1u << 24;   // "one child left to enter below child_base 0": node 0, whatever the octant
     w.pb = 0u; w.pm = 0u; w.sp = 0u; w.occluded = false; w.wide = true;
 }
-__device__ __forceinline__ uint32_t rt_bfi(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); }   // v_bfi_b32
+// (m & a) | (~m & b) as the one instruction it is: from the C expression the compiler keeps ~m in a register and emits v_and +
+// v_and_or, 24 instructions per node step where 12 do
+__device__ __forceinline__ uint32_t rt_bfi(uint32_t m, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ float rt_ub0(uint32_t v) { return (float)(v & 255u); }            // v_cvt_f32_ubyte0..3
 __device__ __forceinline__ float rt_ub1(uint32_t v) { return (float)((v >> 8) & 255u); }
 __device__ __forceinline__ float rt_ub2(uint32_t v) { return (float)((v >> 16) & 255u); }

@@ -6,13 +6,8 @@
 //     Geometry.h:319-438), built iteratively over one index array.  Same cost expression, same
 //     strict '<' tie rule, same stable partition, same "split always attempted" rule, so the
 //     tree -- and therefore the first-visited-wins order of equal-t hits -- is the reference's.
-//  3. Collapse to a 4-wide tree whose child boxes are boxes of reference nodes.  The kernels
-//     only ever apply the reference's own slab expression to those boxes, and a parent box
-//     contains its child box exactly (both are min/max over vertex sets), so "this box passes"
-//     implies "every skipped ancestor passes" for finite rays: the candidate set of triangles is
-//     unchanged.  Single-triangle leaves have an un-initialised (always passing) box upstream
-//     (Geometry.h:401); their slot carries the parent's box, which is the last real test on the
-//     reference's way down to them.
+//  3. The reference-topology node array (DNode2).  What the walk reads -- the 8-wide tree, the walk-ordered
+//     triangle records and the per-triangle gate boxes -- is derived from it on the device (walk_tree.hip).
 #include "scene_build.h"
 
 #include <math.h>
@@ -160,120 +155,6 @@ struct Builder {
     }
 };
 
-// ---- 4-wide collapse -------------------------------------------------------------------------------------------
-// Numbered level by level: node 0 stands for the root; the inner children of a level's nodes, in (parent index, slot)
-// order, are the next level.  The numbering depends on the tree's shape alone, not on how a builder happened to number the
-// binary nodes, so the device-side collapse (bvh_build.hip), which works one level per launch, produces the same array.
-struct Slot { Aabb box; int bnode; /* >= 0: inner reference node to expand */ uint32_t first, count; /* leaf range */ };
-struct WorkItem { int bnode; /* >= 0: a reference node; -1: a leaf range longer than RT_LEAF_MAX, cut in up to four parts */ Aabb box; uint32_t first, count; };
-
-struct Collapser {
-    const std::vector<BNode>& bn;
-    std::vector<DNode4>& out;
-
-    bool single(int i) const { return bn[i].left < 0 && bn[i].count <= 1; }
-    bool is_leaf(int i) const { return bn[i].left < 0; }
-
-    Slot make_slot(int child, const Aabb& parent_box) const {
-        const BNode& c = bn[child];
-        Slot s; s.bnode = -1; s.first = c.first; s.count = c.nleaf;
-        if (is_leaf(child)) { s.box = c.count >= 2 ? c.box : parent_box; return s; }
-        if (single(c.left) && single(c.right)) {  // two always-passing leaves under one tested box: one slot, two triangles
-            s.box = c.box; s.first = bn[c.left].first; s.count = bn[c.left].nleaf + bn[c.right].nleaf; return s;
-        }
-        s.box = c.box; s.bnode = child; s.count = 0;
-        return s;
-    }
-    static void set_child(DNode4& n, int k, const Aabb& b, uint32_t ref) {
-        n.lox[k] = b.lo.x; n.loy[k] = b.lo.y; n.loz[k] = b.lo.z; n.hix[k] = b.hi.x; n.hiy[k] = b.hi.y; n.hiz[k] = b.hi.z;
-        n.child[k] = ref;
-    }
-    static DNode4 empty_node() {
-        // an unused child slot carries the empty box (lo = +inf, hi = -inf): for a finite non-zero 1/dir every entry distance
-        // is +inf and every exit distance -inf, the slot fails by itself and the walk needs no separate "slot in use" test
-        DNode4 n; memset(&n, 0, sizeof(n));
-        const float inf = std::numeric_limits<float>::infinity();
-        for (int k = 0; k < 4; k++) {
-            n.child[k] = RT_REF_EMPTY;
-            n.lox[k] = n.loy[k] = n.loz[k] = inf; n.hix[k] = n.hiy[k] = n.hiz[k] = -inf;
-        }
-        return n;
-    }
-    // the up to four slots of the wide node that stands for `w`
-    int gather(const WorkItem& w, Slot* slots) const {
-        int ns = 0;
-        if (w.bnode < 0) {  // a long leaf range: parts that all carry the leaf's box
-            const uint32_t parts = std::min<uint32_t>(4, (w.count + RT_LEAF_MAX - 1) / RT_LEAF_MAX);
-            for (uint32_t p = 0; p < parts; p++) {
-                const uint32_t b = (uint32_t)((uint64_t)w.count * p / parts), e = (uint32_t)((uint64_t)w.count * (p + 1) / parts);
-                slots[ns].box = w.box; slots[ns].bnode = -1; slots[ns].first = w.first + b; slots[ns].count = e - b; ns++;
-            }
-            return split_leaves(slots, ns);
-        }
-        slots[ns++] = make_slot(bn[w.bnode].left, bn[w.bnode].box);
-        slots[ns++] = make_slot(bn[w.bnode].right, bn[w.bnode].box);
-        while (ns < 4) {  // open the inner slot with the largest box (the first of equals)
-            int pick = -1; float best = -1.0f;
-            for (int i = 0; i < ns; i++)
-                if (slots[i].bnode >= 0) { float a = slots[i].box.area(); if (a > best) { best = a; pick = i; } }
-            if (pick < 0) break;
-            const int e = slots[pick].bnode;
-            const Slot l = make_slot(bn[e].left, bn[e].box), r = make_slot(bn[e].right, bn[e].box);
-            for (int i = ns; i > pick + 1; i--) slots[i] = slots[i - 1];
-            slots[pick] = l; slots[pick + 1] = r; ns++;
-        }
-        return split_leaves(slots, ns);
-    }
-    // Slots that are still free go to the triangles of multi-triangle leaf slots, one triangle each, in slot order: the walk
-    // bounds every leaf slot by its own triangles (k_quantise), so a ray that misses one triangle of a pair no longer tests it.
-    // The parts keep the slot's reference box (the gate of their triangles).
-    static int split_leaves(Slot* slots, int ns) {
-        for (int i = 0; i < ns && ns < 4; i++) {
-            if (slots[i].bnode >= 0 || slots[i].count < 2 || slots[i].count > RT_LEAF_MAX) continue;
-            for (int k = ns; k > i + 1; k--) slots[k] = slots[k - 1];
-            slots[i + 1] = slots[i];
-            slots[i].count = 1; slots[i + 1].first += 1; slots[i + 1].count -= 1; ns++;
-        }
-        return ns;
-    }
-    void run(const WorkItem& root) {
-        std::vector<WorkItem> cur{ root }, next;
-        out.push_back(empty_node());
-        size_t level_base = 0;
-        while (!cur.empty()) {
-            const size_t next_base = level_base + cur.size();
-            next.clear();
-            for (size_t i = 0; i < cur.size(); i++) {
-                Slot slots[4];
-                const int ns = gather(cur[i], slots);
-                DNode4& n = out[level_base + i];
-                for (int k = 0; k < ns; k++) {
-                    uint32_t ref;
-                    if (slots[k].bnode >= 0) { ref = (uint32_t)(next_base + next.size()); next.push_back(WorkItem{ slots[k].bnode, slots[k].box, 0, 0 }); }
-                    else if (slots[k].count <= RT_LEAF_MAX) ref = rt_make_leaf_ref(slots[k].first, slots[k].count);
-                    else { ref = (uint32_t)(next_base + next.size()); next.push_back(WorkItem{ -1, slots[k].box, slots[k].first, slots[k].count }); }
-                    set_child(n, k, slots[k].box, ref);
-                }
-            }
-            out.resize(next_base + next.size(), empty_node());
-            level_base = next_base;
-            cur.swap(next);
-        }
-    }
-};
-
-// Entries a walk can have waiting below wide node `i`: its other children, plus the worst of what a child needs.
-static uint32_t wide_stack_need(const std::vector<DNode4>& n, uint32_t i) {
-    uint32_t used = 0, worst = 0;
-    for (int k = 0; k < 4; k++) {
-        const uint32_t ref = n[i].child[k];
-        if (ref == RT_REF_EMPTY) continue;
-        used++;
-        if (!(ref & RT_REF_LEAF)) worst = std::max(worst, wide_stack_need(n, ref));
-    }
-    return (used ? used - 1 : 0) + worst;
-}
-
 inline void put3(float* d, F3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
 inline float lum(const float* c) { return ((0.2126f * c[0]) + (0.7152f * c[1]) + (0.0722f * c[2])); }  // Colour::Lum (Core.h:89)
 
@@ -281,7 +162,7 @@ inline float lum(const float* c) { return ((0.2126f * c[0]) + (0.7152f * c[1]) +
 
 bool host_scene_build(const rt_scene_desc& d, HostScene& hs, std::string& err, DeviceSceneBuilder device_builder, DeviceGeometry* geom) {
     auto t0 = std::chrono::steady_clock::now();
-    if (d.n_tris > RT_LEAF_FIRST_MASK) { err = "too many triangles (max 2^27-1)"; return false; }
+    if (d.n_tris > RT_MAX_TRIS) { err = "too many triangles (max 2^27-1)"; return false; }
     if (d.n_tris && (!d.verts || !d.tri_material)) { err = "verts/tri_material is NULL"; return false; }
     if (d.n_materials && !d.materials) { err = "materials is NULL"; return false; }
     if (d.n_textures && !d.textures) { err = "textures is NULL"; return false; }
@@ -373,9 +254,8 @@ bool host_scene_build(const rt_scene_desc& d, HostScene& hs, std::string& err, D
     hs.depth2 = b.max_depth; hs.leaves2 = b.leaves; hs.max_leaf2 = b.max_leaf;
     hs.max_stack2 = b.max_depth + 2;
 
-    // triangle records in DFS order + scene bounds (Scene::init, Scene.h:152-158), the reference-topology nodes and the
-    // 4-wide collapse only read the binary tree: the three run side by side, the records on several threads (the partial
-    // bounds are folded in order below)
+    // triangle records in DFS order + scene bounds (Scene::init, Scene.h:152-158) on several threads (the partial bounds are
+    // folded in order below), the reference-topology nodes beside them
     Aabb bounds;
     hs.tris.resize(d.n_tris); hs.trishade.resize(d.n_tris);
     float amax = 0;
@@ -421,28 +301,12 @@ bool host_scene_build(const rt_scene_desc& d, HostScene& hs, std::string& err, D
             put3(o.lo, s.box.lo); put3(o.hi, s.box.hi);
             o.left = s.left; o.right = s.right; o.first = (int32_t)s.first; o.count = (int32_t)s.nleaf; o.pad0 = (int32_t)s.begin; o.pad1 = (int32_t)s.count;
         }
-        // 4-wide tree
-        if (d.n_tris > 0) {
-            Collapser col{ b.nodes, hs.nodes4 };
-            const BNode& root = b.nodes[0];
-            if (root.left < 0 || (col.single(root.left) && col.single(root.right))) {
-                // the whole scene is one leaf slot; a single-triangle root has no real box anywhere above it
-                Aabb box = root.count >= 2 ? root.box : Aabb();
-                if (root.count < 2) { box.lo = f3(-Aabb::FLT_MAX_, -Aabb::FLT_MAX_, -Aabb::FLT_MAX_); box.hi = f3(Aabb::FLT_MAX_, Aabb::FLT_MAX_, Aabb::FLT_MAX_); }
-                if (d.n_tris <= RT_LEAF_MAX) {
-                    hs.nodes4.push_back(Collapser::empty_node());
-                    Collapser::set_child(hs.nodes4[0], 0, box, rt_make_leaf_ref(0, d.n_tris));
-                } else col.run(WorkItem{ -1, box, 0, d.n_tris });
-            } else col.run(WorkItem{ 0, root.box, 0, 0 });
-            hs.max_stack4 = wide_stack_need(hs.nodes4, 0) + 2;
-        }
-        if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "  nodes2 + collapse thread done at %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "  nodes2 thread done at %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     });
     records(0);
     for (auto& t : workers) t.join();
     if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "  records (%u threads) done at %.3f s\n", nthr, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     tree.join();
-    if (hs.nodes4.size() > (1u << 25)) { err = "wide BVH exceeds 2^25 nodes (32-bit node offsets)"; return false; }
     for (uint32_t ti = 0; ti < nthr; ti++) {
         const Aabb& q = part_bounds[ti];   // folded in order with extend's own ternaries: the same bits as one pass, signed zeros included
         bounds.hi = f3(bounds.hi.x > q.hi.x ? bounds.hi.x : q.hi.x, bounds.hi.y > q.hi.y ? bounds.hi.y : q.hi.y, bounds.hi.z > q.hi.z ? bounds.hi.z : q.hi.z);
@@ -451,7 +315,7 @@ bool host_scene_build(const rt_scene_desc& d, HostScene& hs, std::string& err, D
     }
     hs.abs_max = amax;
     put3(hs.bounds_lo, bounds.lo); put3(hs.bounds_hi, bounds.hi);
-    hs.n_tris = d.n_tris; hs.n_nodes4 = (uint32_t)hs.nodes4.size(); hs.n_nodes2 = (uint32_t)hs.nodes2.size();
+    hs.n_tris = d.n_tris; hs.n_nodes2 = (uint32_t)hs.nodes2.size();
     }
     {   // SceneBounds (SceneLoader.h:286-287)
         F3 lo = f3(hs.bounds_lo[0], hs.bounds_lo[1], hs.bounds_lo[2]), hi = f3(hs.bounds_hi[0], hs.bounds_hi[1], hs.bounds_hi[2]);
@@ -460,7 +324,7 @@ bool host_scene_build(const rt_scene_desc& d, HostScene& hs, std::string& err, D
         hs.radius = length(sub(hi, c));
     }
 
-    if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "records + collapse done at %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "records + nodes2 done at %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     // light list: background first if it has power (Scene.h:164), then emissive triangles in caller order (Scene.h:107)
     {
         float power = 0;

@@ -46,7 +46,7 @@ struct rt_scene {
     std::mutex mu;
 };
 
-// walk_tree.hip: gate boxes, the 8-wide walk nodes and the walk-ordered triangle records, from nodes4 + tris on the device
+// walk_tree.hip: gate boxes, the 8-wide walk nodes and the walk-ordered triangle records, from nodes2 + tris on the device
 int rt_build_walk_tree(rt_scene* s);
 // shared launch helpers (intersect.hip)
 int rt_scene_persistent_blocks(const rt_scene* s);

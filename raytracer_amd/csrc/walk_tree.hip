@@ -1,11 +1,11 @@
 // walk_tree.hip — the walk's own view of the tree, derived on the device from what the builders leave there.
 //
 // The builders (scene_build.cpp on the host, bvh_build.hip on the device) produce the triangle records in DFS leaf order
-// (`tris`), the reference-topology binary tree (`nodes2`) and its 4-wide collapse with float boxes (`nodes4`).  The walk is
+// (`tris`) and the reference-topology binary tree (`nodes2`), the same from both.  The walk is
 // only required to be conservative -- rt_settle restores upstream's candidate set per ray from the gate box of the hit it
 // reports (rt_device.h) -- so the tree it descends is built for what the traversal kernels are bound
 // by, instruction issue: few, wide steps and few divergent loads per ray.  This file makes
-//   gate   : per triangle, the float box of its leaf slot in nodes4 (the reference box rt_settle tests),
+//   gate   : per triangle, the box of the last reference node upstream really tests on the way down to it (what rt_settle tests),
 //   nodes8 : the 8-wide tree, 80 B per node (DNode8, rt_common.h), level by level from nodes2: a wide node starts as one
 //            reference node and opens the child with the largest box, one at a time, until eight slots are taken; up to
 //            RT_LEAF_MAX triangles make a leaf slot, bounded by its own triangles; slots that stay free go to the single
@@ -278,7 +278,7 @@ struct Tmp {
 
 }  // namespace
 
-// Fills s->d.gate / nodes8 / trisw / n_nodes8 / walk_stack from s->d.nodes4 and s->d.tris (both already in device memory).
+// Fills s->d.gate / nodes8 / trisw / n_nodes8 / walk_stack from s->d.nodes2 and s->d.tris (both already in device memory).
 int rt_build_walk_tree(rt_scene* s) {
     HostScene& h = s->host;
     DScene& d = s->d;

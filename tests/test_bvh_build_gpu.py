@@ -14,32 +14,32 @@ def both(s):
     return api.Scene(s, device_build=False), api.Scene(s, device_build=True)
 
 
-def same_wide_nodes(h, d):
-    """The 4-wide node arrays of a host-built and a device-built scene, byte for byte: child references and padding as integers;
-    box planes as integers too, except that +0.0 and -0.0 count as the same plane (a min / max over vertices that hold both
-    zeros returns whichever it saw last on the host and the smaller key on the device; no test reads the sign of a zero)."""
-    a, b = h.wide_nodes(), d.wide_nodes()
-    assert len(a) == len(b) and np.array_equal(a["child"], b["child"]) and np.array_equal(a["pad"], b["pad"])
-    ba, bb = a["box"].view(np.uint32), b["box"].view(np.uint32)
-    zero = ((ba & 0x7FFFFFFF) == 0) & ((bb & 0x7FFFFFFF) == 0)
-    assert np.array_equal(ba[~zero], bb[~zero])
-    # what the walk reads is derived from that array on the device (csrc/walk_tree.hip) and must come out the same as well;
-    # the sign of a zero plane can only move a node's origin between +0 and -0
+def same_walk_nodes(h, d):
+    """What the kernels walk, from a host-built and a device-built scene: the reference-topology nodes node for node (the two
+    builders number them differently: compared through the triangle range each node stands for), and the arrays derived from
+    them on the device (csrc/walk_tree.hip: 8-wide nodes, walk-ordered records, gate boxes) byte for byte.  Box planes compare as
+    integers, except that +0.0 and -0.0 count as the same plane (a min / max over vertices that hold both zeros returns
+    whichever it saw last on the host and the smaller key on the device; no test reads the sign of a zero)."""
+    def same_planes(x, y):
+        x, y = x.view(np.uint32), y.view(np.uint32)
+        z = ((x & 0x7FFFFFFF) == 0) & ((y & 0x7FFFFFFF) == 0)
+        return np.array_equal(x[~z], y[~z])
+    ra, rb = h.ref_nodes(), d.ref_nodes()
+    assert len(ra) == len(rb)
+    ka, kb = np.lexsort((-ra["sub_count"], ra["sub_first"])), np.lexsort((-rb["sub_count"], rb["sub_first"]))   # DFS pre-order
+    ra, rb = ra[ka], rb[kb]
+    for f in ("sub_first", "sub_count", "first", "count"):
+        assert np.array_equal(ra[f], rb[f]), f
+    assert np.array_equal(ra["left"] < 0, rb["left"] < 0) and np.array_equal(ra["right"] < 0, rb["right"] < 0)
+    boxed = ra["sub_count"] >= 2                                  # a single-triangle leaf keeps upstream's never-initialised box
+    assert same_planes(ra["lo"][boxed], rb["lo"][boxed]) and same_planes(ra["hi"][boxed], rb["hi"][boxed])
     (na, ga, ta), (nb, gb, tb) = h.walk_nodes(), d.walk_nodes()
     assert len(na) == len(nb)
     for f in na.dtype.names:
-        if f == "org":
-            oa, ob = na["org"].view(np.uint32), nb["org"].view(np.uint32)
-            z = ((oa & 0x7FFFFFFF) == 0) & ((ob & 0x7FFFFFFF) == 0)
-            assert np.array_equal(oa[~z], ob[~z])
-        else:
-            assert np.array_equal(na[f], nb[f]), f
+        assert same_planes(na["org"], nb["org"]) if f == "org" else np.array_equal(na[f], nb[f]), f
     assert np.array_equal(ta.view(np.uint8), tb.view(np.uint8))
-    for f in ("lo", "hi"):
-        x, y = ga[f].view(np.uint32), gb[f].view(np.uint32)
-        z = ((x & 0x7FFFFFFF) == 0) & ((y & 0x7FFFFFFF) == 0)
-        assert np.array_equal(x[~z], y[~z])
-    return len(a)
+    assert same_planes(ga["lo"], gb["lo"]) and same_planes(ga["hi"], gb["hi"])
+    return len(na)
 
 
 @pytest.mark.parametrize("make", [
@@ -53,10 +53,10 @@ def test_device_build_equals_host_build(make):
     s = make()
     h, d = both(s)
     ih, idv = h.info(), d.info()
-    for k in ("n_tris", "n_lights", "bvh2_nodes", "bvh2_depth", "bvh2_leaves", "bvh2_max_leaf", "wide_nodes", "wide_max_stack", "collapse_nodes", "wide_levels"):
+    for k in ("n_tris", "n_lights", "bvh2_nodes", "bvh2_depth", "bvh2_leaves", "bvh2_max_leaf", "wide_nodes", "wide_max_stack", "wide_levels"):
         assert ih[k] == idv[k], k
     assert np.array_equal(h.leaf_order(), d.leaf_order())
-    assert same_wide_nodes(h, d) == ih["collapse_nodes"]
+    assert same_walk_nodes(h, d) == ih["wide_nodes"]
     rays = np.concatenate([scenes.bounce_rays(s, 100000, 5), scenes.primary_rays(s, 50000, 6) if s.cam_P is not None else scenes.bounce_rays(s, 50000, 7)])
     for mode in (0, 1):
         a, b = h.traverse(rays, mode), d.traverse(rays, mode)
@@ -82,7 +82,7 @@ def test_long_leaves_are_cut_the_same_way():
     h, d = both(s)
     assert h.info()["bvh2_max_leaf"] == d.info()["bvh2_max_leaf"]
     assert np.array_equal(h.leaf_order(), d.leaf_order())
-    same_wide_nodes(h, d)
+    same_walk_nodes(h, d)
     rays = scenes.bounce_rays(s, 100000, 5)
     assert np.array_equal(h.traverse(rays).view(np.uint8), d.traverse(rays).view(np.uint8))
     h.close(); d.close()
@@ -93,7 +93,7 @@ def test_tiny_scenes(n):
     s = scenes.random_soup(n, seed=2)
     h, d = both(s)
     assert h.info()["bvh2_nodes"] == d.info()["bvh2_nodes"] and np.array_equal(h.leaf_order(), d.leaf_order())
-    same_wide_nodes(h, d)
+    same_walk_nodes(h, d)
     rays = np.random.default_rng(1).normal(size=(4096, 6)).astype(np.float32)
     assert np.array_equal(h.traverse(rays).view(np.uint8), d.traverse(rays).view(np.uint8))
     h.close(); d.close()
@@ -106,12 +106,12 @@ def test_full_size_bathroom_build_and_time():
     t = time.perf_counter(); d2 = api.Scene(s, device_build=True); td2 = time.perf_counter() - t; d2.close()   # second time: no first-launch cost
     print(f"scene create: host build {th:.2f} s, device build {td:.2f} s, again {td2:.3f} s (n_tris {s.ntris})")
     ih, idv = h.info(), d.info()
-    for k in ("n_tris", "n_lights", "bvh2_nodes", "bvh2_depth", "bvh2_leaves", "bvh2_max_leaf", "wide_nodes", "wide_max_stack", "collapse_nodes", "wide_levels"):
+    for k in ("n_tris", "n_lights", "bvh2_nodes", "bvh2_depth", "bvh2_leaves", "bvh2_max_leaf", "wide_nodes", "wide_max_stack", "wide_levels"):
         assert ih[k] == idv[k], k
     assert np.array_equal(h.leaf_order(), d.leaf_order())
-    assert same_wide_nodes(h, d) == ih["collapse_nodes"]
+    assert same_walk_nodes(h, d) == ih["wide_nodes"]
     assert td2 < 1.0                                       # all-device set-up: 0.05 s on an idle box (0.19 s with the host-side records and collapse of round 1); generous, the box may be loaded
-    assert idv["wide_max_stack"] <= 32 and idv["wide_nodes"] < idv["collapse_nodes"]
+    assert idv["wide_max_stack"] <= 32 and idv["wide_nodes"] < idv["n_tris"] // 4
     rays = scenes.bounce_rays(s, 1 << 20, 3)
     assert np.array_equal(h.traverse(rays).view(np.uint8), d.traverse(rays).view(np.uint8))
     h.close(); d.close()
@@ -125,31 +125,40 @@ def test_full_size_bathroom_build_and_time():
     lambda: scenes.random_soup(1, seed=2),
 ], ids=["cornell", "soup", "lattice", "bathroom", "one-triangle"])
 def test_walk_nodes_bound_what_they_stand_for(make):
-    """The 80-B 8-wide nodes the kernels read (rt_scene_debug_walk_nodes) against the float tree they are derived from
-    (rt_scene_debug_wide_nodes) and the triangles: every slot's grid box contains the vertices of every triangle below it (a leaf
+    """The 80-B 8-wide nodes the kernels read (rt_scene_debug_walk_nodes) against the reference tree they are derived from
+    (rt_scene_debug_ref_nodes) and the triangles: every slot's grid box contains the vertices of every triangle below it (a leaf
     slot's within one grid step); inner children are numbered consecutively from child_base in slot order, leaf triangles
     consecutively from tri_base; every triangle sits in exactly one leaf slot, and its record in the walk-ordered array is its
-    DFS-order record with the rank in place of orig_id; every triangle's gate box is its leaf slot's box in the float tree (what
-    upstream's rayAABB is evaluated on); the stack bound holds for the tree's shape."""
+    DFS-order record with the rank in place of orig_id; every triangle's gate box is the box of the last reference node upstream
+    really tests on the way down to it (its leaf's, or the parent's for a leaf of one triangle: Geometry.h:401, :441-471 --
+    recomputed here from the reference nodes); the stack bound holds for the tree's shape."""
     s = make()
     sc = api.Scene(s)
-    wide = sc.wide_nodes()
+    ref = sc.ref_nodes()
     q, gate, trisw = sc.walk_nodes()
     info = sc.info()
     order = sc.leaf_order()
     v = s.verts[order][:, :, :3].astype(np.float64)            # triangles in DFS leaf order
-    # gate boxes: from the float tree's leaf slots
-    EMPTY, LEAF = 0xFFFFFFFF, 0x80000000
+    # gate boxes, from the reference tree
+    is_leaf = (ref["left"] < 0) & (ref["right"] < 0)
     seen = np.zeros(len(order), bool)
-    for k in range(4):
-        ref = wide["child"][:, k]
-        for i in np.nonzero((ref != EMPTY) & ((ref & LEAF) != 0))[0]:
-            first, cnt = int(ref[i] & 0x07FFFFFF), int((ref[i] >> 27) & 15) + 1
-            assert cnt <= 3
-            assert (gate["lo"][first:first + cnt] == wide["box"][i, 0:3, k]).all() and (gate["hi"][first:first + cnt] == wide["box"][i, 3:6, k]).all()
-            assert not seen[first:first + cnt].any()
-            seen[first:first + cnt] = True
-    assert seen.all(), "a triangle without a leaf slot in the float tree"
+    def put(first, cnt, lo, hi):
+        assert (gate["lo"][first:first + cnt] == lo).all() and (gate["hi"][first:first + cnt] == hi).all()
+        assert not seen[first:first + cnt].any()
+        seen[first:first + cnt] = True
+    if is_leaf[0]:
+        big = np.float32(3.402823466e38)
+        if ref["count"][0] >= 2: put(0, int(ref["count"][0]), ref["lo"][0], ref["hi"][0])
+        else: put(0, int(ref["count"][0]), -big, big)
+    for i in np.nonzero(~is_leaf)[0]:
+        for c in (int(ref["left"][i]), int(ref["right"][i])):
+            if c >= 0 and is_leaf[c]:
+                own = ref["count"][c] >= 2
+                put(int(ref["first"][c]), int(ref["count"][c]), ref["lo"][c] if own else ref["lo"][i], ref["hi"][c] if own else ref["hi"][i])
+                tv = v[ref["first"][c]:ref["first"][c] + ref["count"][c]].reshape(-1, 3)     # and that box does hold its triangles
+                g = gate[int(ref["first"][c])]
+                assert (g["lo"] <= tv.min(0)).all() and (g["hi"] >= tv.max(0)).all()
+    assert seen.all(), "a triangle without a gate box"
     # walk-ordered records
     assert sorted(trisw["rank"].tolist()) == list(range(len(order)))
     assert np.array_equal(trisw["v"].astype(np.float64), v[trisw["rank"]])

@@ -28,7 +28,7 @@ def test_host_builder_reproduces_reference_tree(name):
     order, info = api.host_build_info(s)
     assert (order == g["leaf_order"]).all()
     assert [info["bvh2_depth"], info["bvh2_nodes"], info["bvh2_leaves"]] == g["stats"].tolist()
-    assert info["collapse_nodes"] > 0      # the walk tree itself is derived on the device: no host-only figure for it
+    assert info["wide_nodes"] == 0          # the walk tree is derived on the device: the host-only query has no figure for it
 
 
 def test_host_builder_matches_oracle_on_interior():
@@ -59,7 +59,7 @@ def test_empty_scene_builds():
     s.verts = s.verts[:0]
     s.tri_mat = s.tri_mat[:0]
     order, info = api.host_build_info(s)
-    assert len(order) == 0 and info["n_tris"] == 0 and info["collapse_nodes"] == 0
+    assert len(order) == 0 and info["n_tris"] == 0 and info["wide_nodes"] == 0
 
 
 def test_rng_spec_matches_oracle():
