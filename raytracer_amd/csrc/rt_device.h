@@ -17,6 +17,7 @@
 #define RT_STACK_LDS 12          // 8-byte stack entries per lane kept in LDS (24 KB per 256-thread block)
 #endif
 #define RT_FLT_MAX 3.402823466e+38f
+#define RT_PAD_SCALE_EXACT 6.103515625e-05f   // 2^-14: cull slack of rt_walk_exact (the wide walk's is RT_PAD_SCALE, 2^-17)
 #define RT_INF __builtin_inff()
 
 struct f3 { float x, y, z; };
@@ -204,8 +205,9 @@ __device__ bool rt_walk_reference(const DScene& S, f3 o, f3 dir, float maxT, Hit
 // infinite or huge, slab products can be NaN and box containment no longer implies test monotonicity).  Every node of
 // the reference tree on the way down is tested with the reference's own expression (rt_box_exact), so the candidate
 // set is the reference's by construction; what this walk adds over rt_walk_reference is near-first order and a
-// conservative cull that only looks at the axes where 1/dir is tame (a box is skipped when, grown by the same slack
-// as in the wide walk, it lies entirely behind the origin or entirely beyond the best hit on those axes).  Without
+// conservative cull that only looks at the axes where 1/dir is tame (a box is skipped when, grown by RT_PAD_SCALE_EXACT
+// of the largest coordinate in play -- 2^-14, eight times the wide walk's slack: this walk runs for a handful of rays per
+// frame and keeps round 1's wider margin -- it lies entirely behind the origin or entirely beyond the best hit on those axes).  Without
 // it one such ray pierces thousands of boxes of a 1 M-triangle scene unculled and, alone in its wave, sets the
 // duration of the whole launch: 0.6-2 ms per k_extend launch before, measured.
 template <bool ANY, bool COUNT>
@@ -214,7 +216,7 @@ __device__ bool rt_walk_exact(const DScene& S, f3 o, f3 dir, float maxT, HitRec&
     const f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);  // Ray::init (Geometry.h:23)
     const bool tx = fabsf(inv.x) < 1e18f, ty = fabsf(inv.y) < 1e18f, tz = fabsf(inv.z) < 1e18f;
     const float scale = fmaxf(S.abs_max, fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))));
-    const float delta = scale * 6.103515625e-05f;
+    const float delta = scale * RT_PAD_SCALE_EXACT;
     const f3 pad = mk3(delta * fabsf(inv.x), delta * fabsf(inv.y), delta * fabsf(inv.z));
     auto test = [&](uint32_t ni, float& key) -> bool {
         const float4* q = reinterpret_cast<const float4*>(S.nodes2 + ni);
@@ -309,7 +311,7 @@ struct Walk {
     HitRec best;       // closest hit so far; any hit: best.rank = the blocker that was found
     uint32_t cb, cm;   // cur
     uint32_t pb, pm;   // pend
-    uint32_t sp;
+    uint32_t sp, sb;   // the stack holds entries [sb, sp): pushes and pops at sp; the tail's work stealing takes from sb, the oldest entry (the largest subtree the walk has waiting)
     uint32_t q4;       // the ray's octant (bit a set where dir is non-negative on axis a) in each of the four bytes
     uint32_t mx, my, mz;   // all ones where 1/dir is negative on that axis, else 0: picks a node's hi planes as the near planes
     bool occluded;
@@ -330,7 +332,7 @@ __device__ __forceinline__ void rt_walk_init(const DScene& S, Walk& w, f3 o, f3 
     w.maxT = maxT;
     rt_walk_signs(w);
     w.cb = 0u; w.cm = 1u << 24;   // "one child left to enter below child_base 0": node 0, whatever the octant
-    w.pb = 0u; w.pm = 0u; w.sp = 0u; w.occluded = false; w.wide = true;
+    w.pb = 0u; w.pm = 0u; w.sp = 0u; w.sb = 0u; w.occluded = false; w.wide = true;
 }
 // (m & a) | (~m & b) as the one instruction it is: from the C expression the compiler keeps ~m in a register and emits v_and +
 // v_and_or, 24 instructions per node step where 12 do
@@ -345,7 +347,7 @@ __device__ __forceinline__ float rt_ub2(uint32_t v) { return (float)((v >> 16) &
 __device__ __forceinline__ float rt_ub3(uint32_t v) { return (float)(v >> 24); }
 template <bool ANY>
 __device__ __forceinline__ void rt_pop(Walk& w, TravStack& st) {
-    if (w.sp == 0u) { w.cm = 0u; return; }
+    if (w.sp == w.sb) { w.cm = 0u; w.sp = 0u; w.sb = 0u; return; }
     --w.sp;
     st.get(w.sp, w.cb, w.cm);
 }
@@ -577,11 +579,12 @@ __device__ __forceinline__ void rt_settle(const DScene& S, Walk& w, bool& visibl
 #endif
 
 // Tail: once the source is drained a wave is left with its slowest walks -- a few rays that take 1000+ steps where the mean
-// is 50 -- and the launch lasts until they end.  From then on idle lanes take work from busy ones: every RT_STEAL_EVERY steps
-// a lane that holds a walk hands the top entry of its stack (the subtree it would enter next) to a free lane, which gets a
-// copy of the ray and the best hit so far and walks that subtree on its own.  The parts of one item are folded together when
-// the wave is done: closest hit = the minimum by (t, rank), the order the single walk applies; any hit = OR.  A part can only
-// miss hits that its copy of best.t already beats, so the result is the single walk's, bit for bit.
+// is 25 -- and the launch lasts until they end.  From then on idle lanes take work from busy ones: every RT_STEAL_EVERY steps
+// a lane that holds a walk hands the oldest entry of its stack (siblings high up in the tree: the largest piece of work it
+// has waiting) to a free lane, which gets a copy of the ray and the best hit so far and walks that subtree on its own.  The
+// parts of one item are folded together as they end (closest hit = the minimum by (t, rank), the order the single walk
+// applies; any hit = OR), a lane that has ended a part is free to steal again, and the lane that ends the last part retires
+// the item.  A part can only miss hits that its copy of best.t already beats, so the result is the single walk's, bit for bit.
 #ifndef RT_TAIL_STEAL
 #define RT_TAIL_STEAL 1
 #endif
@@ -637,14 +640,26 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
         }
     }
     if (RT_TAIL_STEAL) {
-        // every lane is busy (walking) or free here: finished lanes retired above
-        unsigned long long split = 0;   // lanes whose result is one part of an item (wave-uniform)
+        // Every lane is busy (walking its own item) or free here: finished lanes retired above.  From now on an item can be in
+        // several lanes at once.  It keeps one record in LDS, in the slot of the lane that held it when the tail began (`own`):
+        // the best answer of the parts that have ended, as one 64-bit key so that an LDS atomic min folds a part in -- closest
+        // hit: (t, DFS rank), the order the single walk applies; any hit: the blocker's rank, or all ones for "visible" -- and
+        // the number of parts still walking.  The lane that ends the last part retires the item; every lane that ends a part
+        // is free at once and steals again.  Only this wave touches its 64 slots, and a wave's LDS operations execute in
+        // program order, so no barrier is needed.
+        __shared__ unsigned long long tail_key[RT_BLOCK];
+        __shared__ uint32_t tail_parts[RT_BLOCK], tail_item[RT_BLOCK];
+        const uint32_t wbase = threadIdx.x & ~63u;
+        uint32_t own = lane;
+        tail_key[threadIdx.x] = ~0ULL; tail_parts[threadIdx.x] = busy ? 1u : 0u; tail_item[threadIdx.x] = item;
         for (uint32_t round = 0;; round++) {
-            const unsigned long long bm = __ballot(busy);
-            if (!bm) break;
+            if (!__ballot(busy)) break;
+            bool ended = false;
             if ((round % (uint32_t)RT_STEAL_EVERY) == 0u) {
-                const unsigned long long fm = __ballot(!busy && !done);      // free: no walk, no result to keep
-                const unsigned long long dm = __ballot(busy && w.sp >= 1u);  // donors: a subtree waiting on the stack
+                // any hit: a blocker found by one part ends the others
+                if (ANY && busy && *(volatile unsigned long long*)&tail_key[wbase + own] != ~0ULL) ended = true;
+                const unsigned long long fm = __ballot(!busy);                          // free: no walk
+                const unsigned long long dm = __ballot(busy && !ended && w.sp > w.sb);  // donors: a subtree waiting on the stack
                 uint32_t n = (uint32_t)__popcll(fm), nd = (uint32_t)__popcll(dm);
                 n = n < nd ? n : nd;
                 if (n) {
@@ -658,57 +673,54 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
                         bits &= bits - 1ULL;
                     }
                     uint32_t give_b = 0, give_m = 0;
-                    if (donor) st.get(--w.sp, give_b, give_m);
+                    if (donor) {   // the oldest entry: siblings high up in the tree
+                        st.get(w.sb, give_b, give_m);
+                        if (++w.sb == w.sp) { w.sp = 0u; w.sb = 0u; }
+                    }
                     // the ray and what is known about it so far travel by shuffle; non-thieves read themselves
                     const f3 o_ = rt_shfl_f3(w.o, from), d_ = rt_shfl_f3(w.dir, from), i_ = rt_shfl_f3(w.inv, from), p_ = rt_shfl_f3(w.pad, from);
                     const float mt_ = rt_shfl_f(w.maxT, from);
                     const float bt_ = rt_shfl_f(w.best.t, from), bu_ = rt_shfl_f(w.best.u, from), bv_ = rt_shfl_f(w.best.v, from);
                     const uint32_t br_ = (uint32_t)__shfl((int)w.best.rank, (int)from);
-                    const uint32_t it_ = (uint32_t)__shfl((int)item, (int)from);
+                    const uint32_t own_ = (uint32_t)__shfl((int)own, (int)from);
                     const uint32_t cb_ = (uint32_t)__shfl((int)give_b, (int)from), cm_ = (uint32_t)__shfl((int)give_m, (int)from);
                     if (thief) {
                         w.o = o_; w.dir = d_; w.inv = i_; w.pad = p_; w.maxT = mt_;
-                        w.best.t = bt_; w.best.u = bu_; w.best.v = bv_; w.best.rank = br_;
+                        w.best.t = bt_; w.best.u = bu_; w.best.v = bv_; w.best.rank = br_;   // the donor's best so far: culls, and folds in harmlessly
                         rt_walk_signs(w);
-                        w.cb = cb_; w.cm = cm_; w.pb = 0u; w.pm = 0u; w.sp = 0; w.occluded = false; w.wide = true;
+                        w.cb = cb_; w.cm = cm_; w.pb = 0u; w.pm = 0u; w.sp = 0u; w.sb = 0u; w.occluded = false; w.wide = true;
                         if (rt_cur_is_tris(w)) { w.pb = w.cb; w.pm = w.cm; w.cm = 0u; }
-                        item = it_; busy = true; visible = true;
+                        own = own_; busy = true; visible = true;
+                        atomicAdd(&tail_parts[wbase + own], 1u);
                         if (COUNT) c_mine = 0;
                     }
-                    split |= __ballot(thief || donor);
                 }
             }
             if (COUNT) { c_slots++; c_busy += busy ? 1u : 0u; c_mine += busy ? 1u : 0u; c_max = c_mine > c_max ? c_mine : c_max; }
-            if (rt_vote_step<ANY, COUNT>(S, w, busy, st, cn, ct)) {
-                busy = false; done = true;
+            if (rt_vote_step<ANY, COUNT>(S, w, busy && !ended, st, cn, ct)) {
+                ended = true;
                 if (ANY) visible = !w.occluded;
-            }
-        }
-        // results that were never part of a split retire together
-        if (done && !((split >> lane) & 1ULL)) { rt_settle<ANY, COUNT>(S, w, visible, spill2, gstride, cn, ct, c_refused); job.retire(item, w, visible); done = false; }
-        unsigned long long hm = __ballot(done);
-        while (hm) {
-            const uint32_t leader = (uint32_t)__ffsll((long long)hm) - 1u;
-            const uint32_t it = (uint32_t)__shfl((int)item, (int)leader);
-            const unsigned long long same = __ballot(done && item == it);
-            if (ANY) {
-                const unsigned long long occ = __ballot(done && item == it && !visible);   // parts that found a blocker
-                if (occ) {
-                    const uint32_t r2 = (uint32_t)__shfl((int)w.best.rank, (int)((uint32_t)__ffsll((long long)occ) - 1u));
-                    if (lane == leader) { visible = false; w.best.rank = r2; }   // rt_settle checks that blocker's gate box
-                }
-            } else {
-                unsigned long long rest = same & ~(1ULL << leader);
-                while (rest) {
-                    const uint32_t l = (uint32_t)__ffsll((long long)rest) - 1u;
-                    const float t2 = rt_shfl_f(w.best.t, l), u2 = rt_shfl_f(w.best.u, l), v2 = rt_shfl_f(w.best.v, l);
-                    const uint32_t r2 = (uint32_t)__shfl((int)w.best.rank, (int)l);
-                    if (lane == leader && (t2 < w.best.t || (t2 == w.best.t && r2 < w.best.rank))) { w.best.t = t2; w.best.u = u2; w.best.v = v2; w.best.rank = r2; }
-                    rest &= rest - 1ULL;
+            } else if (ended) visible = true;   // cut short by another part's blocker: nothing of its own to report
+            if (ended) {
+                busy = false;
+                const uint32_t slot = wbase + own;
+                const unsigned long long key = ANY ? (visible ? ~0ULL : (unsigned long long)w.best.rank)
+                                                   : (((unsigned long long)__float_as_uint(w.best.t + 0.0f) << 32) | (unsigned long long)w.best.rank);
+                atomicMin(&tail_key[slot], key);
+                if (atomicSub(&tail_parts[slot], 1u) == 1u) {   // the item's last part: this lane holds its ray and retires it
+                    const unsigned long long k = *(volatile unsigned long long*)&tail_key[slot];
+                    const uint32_t rank = (uint32_t)k;
+                    if (ANY) { visible = k == ~0ULL; w.best.rank = rank; }
+                    else if (rank != w.best.rank) {
+                        // another part won: the same test on the same record gives its t, u, v again, bit for bit
+                        w.best.t = RT_FLT_MAX; w.best.u = 0; w.best.v = 0; w.best.rank = rank;
+                        if (rank != 0xFFFFFFFFu) { float t, u, v; (void)rt_tri_test(S.tris + rank, w.o, w.dir, t, u, v); w.best.t = t; w.best.u = u; w.best.v = v; }
+                    }
+                    w.wide = true;
+                    rt_settle<ANY, COUNT>(S, w, visible, spill2, gstride, cn, ct, c_refused);
+                    job.retire(*(volatile uint32_t*)&tail_item[slot], w, visible);
                 }
             }
-            if (lane == leader) { w.wide = true; rt_settle<ANY, COUNT>(S, w, visible, spill2, gstride, cn, ct, c_refused); job.retire(item, w, visible); }
-            hm &= ~same;
         }
     }
     if (COUNT) {

@@ -301,8 +301,8 @@ def open_box(width=96, height=96, background="env"):
 def interior(variant="bathroom", detail=1.0, width=1920, height=1080, seed=1, conductor=False, dielectric=False, glazed=False):
     """Closed-room stand-in for the bathroom / living-room scenes: ~1.0 M triangles at detail=1
     (triangle count scales ~detail^2), tessellated displaced fixtures, thin slats (blinds), glass bulbs,
-    a mirror, a tiled floor with a bilinear checker texture, plastic/diffuse/glass/mirror materials and
-    four ceiling panels.  Vertices carry a <=1e-3 seeded jitter so there are no exact coplanar duplicates.
+    a mirror, a tiled floor with a bilinear checker texture, diffuse / Oren-Nayar / glass / mirror materials (plastic
+    and the rough dielectric only in the opt-in variants below) and four ceiling panels.  Vertices carry a <=1e-3 seeded jitter so there are no exact coplanar duplicates.
 
     The default scene holds only BSDFs whose upstream estimators stay finite (diffuse, Oren-Nayar, glass, mirror), so that
     its film is finite and the converged-image gate can run on it.  Upstream's non-finite cases are opt-in variants of the

@@ -37,3 +37,22 @@ for i in range(len(q)):
             node_area[q["child_base"][i] + k] = area[i, sl]; k += 1
 w = node_area / node_area.sum()
 print("share of (area-weighted) node visits by used slots:", [round(float(w[fill == f].sum()), 3) for f in range(9)], "mean fill of a visited node", float((w * fill).sum()))
+# what the 8-bit grid costs: box area (~ visit probability for random rays) of the slots as the walk sees them against their exact boxes
+glo = q["org"][:, :, None].astype(np.float64) + q["lo"].astype(np.float64) * step[:, :, None]
+ghi = q["org"][:, :, None].astype(np.float64) + q["hi"].astype(np.float64) * step[:, :, None]
+tv = trisw["v"].astype(np.float64)                       # (n, 3 verts, 3)
+tlo, thi = tv.min(1), tv.max(1)
+ex_area_leaf, gr_area_leaf = 0.0, 0.0
+nodes_i, slots_i = np.nonzero(leaf)
+off = (meta[nodes_i, slots_i] & 0x1F); c = cnt[nodes_i, slots_i]
+pos = q["tri_base"][nodes_i].astype(np.int64) + off
+lo_e = tlo[pos].copy(); hi_e = thi[pos].copy()
+for k in (1, 2):
+    m = c > k
+    lo_e[m] = np.minimum(lo_e[m], tlo[pos[m] + k]); hi_e[m] = np.maximum(hi_e[m], thi[pos[m] + k])
+e = hi_e - lo_e
+ex = 2 * (e[:, 0] * e[:, 1] + e[:, 1] * e[:, 2] + e[:, 0] * e[:, 2])
+g = (ghi - glo)[nodes_i, :, slots_i]
+gr = 2 * (g[:, 0] * g[:, 1] + g[:, 1] * g[:, 2] + g[:, 0] * g[:, 2])
+print("leaf slots: grid-box area / exact-box area, summed:", gr.sum() / ex.sum(), " median per slot:", float(np.median(gr / np.maximum(ex, 1e-30))),
+      " (triangle-count weighted tests: grid", float((gr * c).sum() / root), "exact", float((ex * c).sum() / root), ")")
