@@ -589,7 +589,7 @@ __device__ __forceinline__ void rt_settle(const DScene& S, Walk& w, bool& visibl
 #define RT_TAIL_STEAL 1
 #endif
 #ifndef RT_STEAL_EVERY
-#define RT_STEAL_EVERY 4
+#define RT_STEAL_EVERY 2
 #endif
 __device__ __forceinline__ float rt_shfl_f(float v, uint32_t src) { return __shfl(v, (int)src); }
 __device__ __forceinline__ f3 rt_shfl_f3(f3 v, uint32_t src) { return mk3(__shfl(v.x, (int)src), __shfl(v.y, (int)src), __shfl(v.z, (int)src)); }
