@@ -246,12 +246,13 @@ def main():
                 "film_mean": film_mean, "film_median": film_median, "film_nonfinite_values": film_nan,
             },
             "roofline": {
-                # what limits the dominant kernel: instruction issue, not HBM or MFMA.  By the PMC counters of this command (profiles/)
-                # VALU issue slots are full and the texture-address unit is busy 70 % of the time; by experiment
-                # the kernel's time follows the number of divergent vector-memory instructions per step
+                # what limits the dominant kernel: VALU instruction issue, not HBM or MFMA.  By the PMC counters of this command (profiles/)
+                # VALU issue slots are full with 37 of 64 lanes live per instruction; a cycle model of instructions per step x steps per
+                # ray / lanes served reproduces the kernel's time
                 "bound": "issue",
-                "bound_is": "instruction issue (VALU slots + divergent vector-memory instructions through the TA), neither HBM nor MFMA: one more dwordx4 per node step "
-                            "costs +17 % of the kernel, 12 % more VALU instructions +3 %, fabric traffic is < 0.2 of the HBM peak",
+                "bound_is": "VALU instruction issue, neither HBM nor MFMA: cycles per ray = sum over step kinds of (lane-steps per ray / lanes served per wave step) x "
+                            "instructions per step x 4 reproduces the kernel's time (8-wide node step 330 instructions, triangle step 140, 36 / 30 of 64 lanes served); "
+                            "fabric traffic is < 0.25 of the HBM peak",
                 "kernel": "k_extend<false,false,0> (closest-hit walk over the 8-wide quantised tree)",
                 # the SURVEY 8(d) figure: ALGORITHMIC bytes (every 80-B node and 64-B triangle fetch counted, cache hits included)
                 # per launch / average launch duration by HIP events over the timed regions, against the HBM peak

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy the judged summaries of tools/final_measure.sh from gpurun_out/final (scratch) into profiles/ (tracked).
 set -e
-src=gpurun_out/final; dst=profiles; tag=${1:-r02}
+src=gpurun_out/final; dst=profiles; tag=${1:-r03}
 cp $src/prof/vm_kernel_stats.csv $dst/${tag}_bench_kernel_stats.csv
 cp $src/bench_under_rocprof.json $dst/${tag}_bench_under_rocprof.json
 cp $src/bench.json $dst/${tag}_bench.json
