@@ -7,10 +7,10 @@
 // by, instruction issue: few, wide steps and few divergent loads per ray.  This file makes
 //   gate   : per triangle, the box of the last reference node upstream really tests on the way down to it (what rt_settle tests),
 //   nodes8 : the 8-wide tree, 80 B per node (DNode8, rt_common.h), level by level from nodes2: a wide node starts as one
-//            reference node and opens the child with the largest box, one at a time, until eight slots are taken; up to
-//            RT_LEAF_MAX triangles make a leaf slot, bounded by its own triangles; slots that stay free go to the single
-//            triangles of multi-triangle leaf slots; children are put into the slot whose octant (relative to the node's
-//            centre) they lie in, and numbered consecutively,
+//            reference node and cuts slots in two -- a child node into the reference node's children, a leaf slot of 2-3
+//            triangles into tighter boxes -- whichever saves most by box area, until eight slots are taken (w8_gather); up to
+//            RT_LEAF_MAX triangles make a leaf slot, bounded by its own triangles; children are put into the slot whose
+//            octant (relative to the node's centre) they lie in, and numbered consecutively,
 //   trisw  : the triangle records in the order nodes8's leaf slots name them, DFS rank inside.
 // One implementation serves both builders and reads only the tree's shape, its boxes and the triangles, so device build ==
 // host build holds for these arrays by construction (tests/test_bvh_build_gpu.py still compares them).
@@ -26,6 +26,12 @@
 #include "rt_device.h"
 #include "scene_dev.h"
 
+// What opening a child node inside its parent is worth against cutting a leaf slot, per unit of box area (w8_gather).
+// 2 / 1 / 0.5 / 0.25 on the bench scene: 7.3 / 6.7 / 5.9 / 5.5 triangle tests and 14.5 / 14.6 / 14.9 / 15.4 node steps per ray of
+// the frame, 4318 / 4357 / 4407 / 4377 Mrays/s (largest box first, leaf slots cut last: 7.9 / 14.5, 4234).
+#ifndef RT_W8_CNODE
+#define RT_W8_CNODE 0.5f
+#endif
 namespace {
 
 // A slot stands for a run of triangles in DFS rank order: everything below a reference node (bnode >= 0), or a part of a
@@ -51,63 +57,61 @@ __device__ inline void w8_range_box(const DTri* __restrict__ tris, uint32_t firs
 // What the walk culls with.  A child node: the reference node's box (the bounds of every vertex below it; a long leaf's
 // parts: the bounds of their own triangles).  A leaf slot: the bounds of its triangles' vertices -- what a hit needs is
 // that the slot's box holds the triangle; its reference box (the gate) can be far larger: a single-triangle leaf has none
-// of its own upstream (Geometry.h:401), a one-triangle scene none at all.  BOXES = false skips what the count pass does not read.
-template <bool BOXES>
+// of its own upstream (Geometry.h:401), a one-triangle scene none at all.
 __device__ inline W8Slot w8_slot_of_node(const DNode2* __restrict__ n2, const DTri* __restrict__ tris, int32_t node) {
     const DNode2 c = n2[node];
     W8Slot s; s.bnode = node; s.first = (uint32_t)c.pad0; s.count = (uint32_t)c.pad1;
     if (s.count > RT_LEAF_MAX) { for (int a = 0; a < 3; a++) { s.lo[a] = c.lo[a]; s.hi[a] = c.hi[a]; } }
-    else if (BOXES) w8_range_box(tris, s.first, s.count, s.lo, s.hi);
+    else w8_range_box(tris, s.first, s.count, s.lo, s.hi);
     return s;
 }
-template <bool BOXES>
 __device__ inline W8Slot w8_slot_of_range(const DTri* __restrict__ tris, uint32_t first, uint32_t count) {
     W8Slot s; s.bnode = -1; s.first = first; s.count = count;
-    if (BOXES || count > RT_LEAF_MAX) w8_range_box(tris, first, count, s.lo, s.hi);
+    w8_range_box(tris, first, count, s.lo, s.hi);
     return s;
 }
-// The up to eight slots of the wide node that stands for `item`: starting from the item itself, the child node with the
-// largest box (the first of equals) is opened -- a reference node into its two children, a long leaf into two halves --
-// until eight slots are taken or only leaf slots are left; slots that are still free then go to the single triangles of
-// multi-triangle leaf slots, in slot order: every leaf slot is bounded by its own triangles, so a ray that misses one
-// triangle of a pair no longer tests it.  Slots keep the left-to-right order of the reference tree.
-template <bool BOXES>
+// a slot cut in two: a reference node into its children, a long leaf (or a part of one) into halves, a leaf slot that is no
+// reference node into its first triangle and the rest
+__device__ inline void w8_cut(const DNode2* __restrict__ n2, const DTri* __restrict__ tris, const W8Slot& e, W8Slot& l, W8Slot& r) {
+    if (e.bnode >= 0) {
+        const DNode2 b = n2[e.bnode];
+        if (b.left >= 0 && b.right >= 0) { l = w8_slot_of_node(n2, tris, b.left); r = w8_slot_of_node(n2, tris, b.right); return; }
+    }
+    const uint32_t h = e.count > RT_LEAF_MAX ? e.count / 2u : 1u;
+    l = w8_slot_of_range(tris, e.first, h); r = w8_slot_of_range(tris, e.first + h, e.count - h);
+}
+// The up to eight slots of the wide node that stands for `item`.  Starting from the item itself, slots are cut in two, the cut
+// that saves most first, until eight are taken or no cut saves anything.  Cutting a child node (more than RT_LEAF_MAX
+// triangles) brings its children up into this node: worth its box area * RT_W8_CNODE.  Cutting a leaf slot of 2-3 triangles
+// spares the rays that cross the slot's box but not the boxes of its parts their triangle tests: worth area * triangles of the
+// slot minus the same of the parts (every leaf slot is bounded by its own triangles' vertices).  One queue for both: near the
+// bottom of the tree a tight box around one triangle is often worth more than opening one more small child, higher up never.
+// Slots keep the left-to-right order of the reference tree.  Both passes of a level call this and must decide alike: it
+// reads only the tree and the triangles.
 __device__ int w8_gather(const DNode2* __restrict__ n2, const DTri* __restrict__ tris, const W8Item& item, W8Slot* s) {
     int ns = 1;
     s[0].bnode = item.bnode; s[0].first = item.first; s[0].count = item.count;
     for (int a = 0; a < 3; a++) { s[0].lo[a] = -RT_INF; s[0].hi[a] = RT_INF; }   // the item itself is always opened first
-    if (item.count <= RT_LEAF_MAX) s[0] = w8_slot_of_range<BOXES>(tris, item.first, item.count);   // a scene of 1-3 triangles
+    if (item.count <= RT_LEAF_MAX) s[0] = w8_slot_of_range(tris, item.first, item.count);   // a scene of 1-3 triangles
     while (ns < 8) {
-        int pick = -1; float best = -1.0f;
+        int pick = -1; float best = 0.0f;
         for (int i = 0; i < ns; i++) {
-            if (s[i].count <= RT_LEAF_MAX) continue;
-            float a = w8_area(s[i]);
-            if (!(a == a)) a = RT_INF;            // inf - inf: the item itself
-            if (a > best) { best = a; pick = i; }
+            float gain;
+            if (s[i].count > RT_LEAF_MAX) {
+                gain = w8_area(s[i]) * (float)(RT_W8_CNODE);
+                if (!(gain == gain)) gain = RT_INF;            // inf - inf: the item itself
+            } else if (s[i].count >= 2u) {
+                W8Slot a, b;
+                w8_cut(n2, tris, s[i], a, b);
+                gain = w8_area(s[i]) * (float)s[i].count - (w8_area(a) * (float)a.count + w8_area(b) * (float)b.count);
+            } else continue;
+            if (gain > best) { best = gain; pick = i; }
         }
-        if (pick < 0) break;
-        const W8Slot e = s[pick];
+        if (pick < 0) break;   // a child node with a box of no area stays a child: it is the item of its own node, and opened there
         W8Slot l, r;
-        bool halves = e.bnode < 0;
-        if (!halves) {
-            const DNode2 b = n2[e.bnode];
-            if (b.left >= 0 && b.right >= 0) { l = w8_slot_of_node<BOXES>(n2, tris, b.left); r = w8_slot_of_node<BOXES>(n2, tris, b.right); }
-            else halves = true;                   // a long leaf of the reference tree
-        }
-        if (halves) {
-            const uint32_t h = e.count / 2u;
-            l = w8_slot_of_range<BOXES>(tris, e.first, h); r = w8_slot_of_range<BOXES>(tris, e.first + h, e.count - h);
-        }
+        w8_cut(n2, tris, s[pick], l, r);
         for (int i = ns; i > pick + 1; i--) s[i] = s[i - 1];
         s[pick] = l; s[pick + 1] = r; ns++;
-    }
-    for (int i = 0; i < ns && ns < 8; i++) {
-        if (s[i].count < 2u || s[i].count > RT_LEAF_MAX) continue;
-        for (int k = ns; k > i + 1; k--) s[k] = s[k - 1];
-        const uint32_t first = s[i].first, count = s[i].count;
-        s[i] = w8_slot_of_range<BOXES>(tris, first, 1u);
-        s[i + 1] = w8_slot_of_range<BOXES>(tris, first + 1u, count - 1u);
-        ns++;
     }
     return ns;
 }
@@ -119,7 +123,7 @@ __global__ void k8_count(uint32_t n_items, const DNode2* __restrict__ n2, const 
     if (i > n_items) return;
     if (i == n_items) { cnt_inner[i] = 0u; cnt_tris[i] = 0u; return; }   // the scans' extra entry: its exclusive sum is the level's total
     W8Slot s[8];
-    const int ns = w8_gather<false>(n2, tris, items[i], s);
+    const int ns = w8_gather(n2, tris, items[i], s);
     uint32_t ci = 0, ct = 0;
     for (int k = 0; k < ns; k++) {
         if (s[k].count <= RT_LEAF_MAX) ct += s[k].count; else ci++;
@@ -137,7 +141,7 @@ __global__ void k8_emit(uint32_t n_items, uint32_t level_base, uint32_t next_bas
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_items) return;
     W8Slot s[8];
-    const int ns = w8_gather<true>(n2, tris, items[i], s);
+    const int ns = w8_gather(n2, tris, items[i], s);
     float nlo[3] = { RT_INF, RT_INF, RT_INF }, nhi[3] = { -RT_INF, -RT_INF, -RT_INF };
     for (int k = 0; k < ns; k++)
         for (int a = 0; a < 3; a++) { nlo[a] = fminf(nlo[a], s[k].lo[a]); nhi[a] = fmaxf(nhi[a], s[k].hi[a]); }
