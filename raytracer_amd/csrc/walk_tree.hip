@@ -80,24 +80,18 @@ __device__ inline void w8_cut(const DNode2* __restrict__ n2, const DTri* __restr
     const uint32_t h = e.count > RT_LEAF_MAX ? e.count / 2u : 1u;
     l = w8_slot_of_range(tris, e.first, h); r = w8_slot_of_range(tris, e.first + h, e.count - h);
 }
-// The up to eight slots of the wide node that stands for `item`.  Starting from the item itself, slots are cut in two, the cut
-// that saves most first, until eight are taken or no cut saves anything.  Cutting a child node (more than RT_LEAF_MAX
-// triangles) brings its children up into this node: worth its box area * RT_W8_CNODE.  Cutting a leaf slot of 2-3 triangles
-// spares the rays that cross the slot's box but not the boxes of its parts their triangle tests: worth area * triangles of the
-// slot minus the same of the parts (every leaf slot is bounded by its own triangles' vertices).  One queue for both: near the
-// bottom of the tree a tight box around one triangle is often worth more than opening one more small child, higher up never.
-// Slots keep the left-to-right order of the reference tree.  Both passes of a level call this and must decide alike: it
-// reads only the tree and the triangles.
-__device__ int w8_gather(const DNode2* __restrict__ n2, const DTri* __restrict__ tris, const W8Item& item, W8Slot* s) {
-    int ns = 1;
-    s[0].bnode = item.bnode; s[0].first = item.first; s[0].count = item.count;
-    for (int a = 0; a < 3; a++) { s[0].lo[a] = -RT_INF; s[0].hi[a] = RT_INF; }   // the item itself is always opened first
-    if (item.count <= RT_LEAF_MAX) s[0] = w8_slot_of_range(tris, item.first, item.count);   // a scene of 1-3 triangles
+// Greedy cuts: slots are cut in two, the cut that saves most first, until eight are taken or no cut saves anything.  Cutting
+// a child node (more than RT_LEAF_MAX triangles; only with `nodes`) brings its children up into this node: worth its box
+// area * RT_W8_CNODE.  Cutting a leaf slot of 2-3 triangles spares the rays that cross the slot's box but not the boxes of its
+// parts their triangle tests: worth area * triangles of the slot minus the same of the parts (every leaf slot is bounded by
+// its own triangles' vertices).  Slots keep the left-to-right order of the reference tree.
+__device__ int w8_greedy(const DNode2* __restrict__ n2, const DTri* __restrict__ tris, W8Slot* s, int ns, bool nodes) {
     while (ns < 8) {
         int pick = -1; float best = 0.0f;
         for (int i = 0; i < ns; i++) {
             float gain;
             if (s[i].count > RT_LEAF_MAX) {
+                if (!nodes) continue;
                 gain = w8_area(s[i]) * (float)(RT_W8_CNODE);
                 if (!(gain == gain)) gain = RT_INF;            // inf - inf: the item itself
             } else if (s[i].count >= 2u) {
@@ -116,14 +110,126 @@ __device__ int w8_gather(const DNode2* __restrict__ n2, const DTri* __restrict__
     return ns;
 }
 
+// ---- the collapse plan: which reference nodes become slots of which wide node, chosen to minimise the surface-area cost of
+// the walk (Ylitie, Karras & Laine 2017, section 3.1, on this walk's slots).  Bottom-up over the reference tree, per node n and
+// slot budget i = 1..7:  C(n, i) = the cheapest way to stand for n's subtree with at most i slots of some wide node,
+//   C(n, 1) = area(n) * triangles(n)                              when n holds at most RT_LEAF_MAX triangles: a leaf slot
+//           = area(n) * RT_W8_DP_CNODE + min_k C(l, k) + C(r, 8 - k)  else: a child node, its eight slots shared out below
+//   C(n, i) = min(C(n, i - 1), min_k C(l, k) + C(r, i - k))        n's two children share the i slots
+// in units of one triangle test per unit of box area.  The plan word of a node keeps the argmins: for j = 2..8 slots shared out,
+// how many go left (3 bits each), and for a budget of i = 2..7 how many of them are really used (3 bits each).
+#ifndef RT_W8_DP
+#define RT_W8_DP 1
+#endif
+#ifndef RT_W8_DP_CNODE
+#define RT_W8_DP_CNODE 1.5f   // a node step in triangle tests.  1 / 1.5 / 2 / 3 on the bench scene: 14.8 / 14.6 / 14.4 / 14.1 node steps and 4.7 / 5.0 / 5.4 / 6.1 triangle tests per ray of the frame, 4599 / 4585 / 4574 / 4519 Mrays/s (greedy cuts alone: 14.9 / 5.9, 4419)
+#endif
+struct W8Cost { float c[7]; };
+__device__ __forceinline__ uint32_t w8_plan_left(unsigned long long pl, uint32_t j) { return (uint32_t)(pl >> (3u * (j - 2u))) & 7u; }
+__device__ __forceinline__ uint32_t w8_plan_used(unsigned long long pl, uint32_t i) { return ((uint32_t)(pl >> (21u + 3u * (i - 2u))) & 7u) + 1u; }
+
+__global__ void k8_parents(uint32_t n, const DNode2* __restrict__ n2, int32_t* __restrict__ parent) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (i == 0u) parent[0] = -1;
+    const DNode2 b = n2[i];
+    if (b.left >= 0 && b.right >= 0) { parent[b.left] = (int32_t)i; parent[b.right] = (int32_t)i; }
+}
+// One thread per leaf of the reference tree climbs towards the root; of the two threads that reach a node the second one
+// finds both children done and goes on (the first one stops), so every inner node is computed once, after its children.
+__global__ void k8_plan(uint32_t n, const DNode2* __restrict__ n2, const DTri* __restrict__ tris, const int32_t* __restrict__ parent,
+                        uint32_t* __restrict__ arrive, W8Cost* cost, unsigned long long* __restrict__ plan) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    {
+        const DNode2 b = n2[i];
+        if (b.left >= 0 && b.right >= 0) return;
+        W8Slot s = w8_slot_of_range(tris, (uint32_t)b.pad0, (uint32_t)b.pad1);
+        float c = w8_area(s) * (float)s.count;
+        if (s.count > RT_LEAF_MAX) c = (w8_area(s) * (float)(RT_W8_DP_CNODE)) + (c * 0.5f);   // a long leaf: a child node of halves
+        W8Cost o;
+        for (int k = 0; k < 7; k++) o.c[k] = c;
+        cost[i] = o;
+    }
+    int32_t node = (int32_t)i;
+    for (;;) {
+        const int32_t p = parent[node];
+        if (p < 0) break;
+        __threadfence();
+        if (atomicAdd(&arrive[p], 1u) == 0u) break;
+        __threadfence();
+        const DNode2 b = n2[p];
+        const W8Cost cl = cost[b.left], cr = cost[b.right];
+        float D[9]; uint32_t K[9];
+        for (uint32_t j = 2; j <= 8; j++) {
+            D[j] = RT_INF; K[j] = 1u;
+            for (uint32_t k = (j > 7u ? j - 7u : 1u); k <= 7u && k < j; k++) {
+                const float c = cl.c[k - 1] + cr.c[j - k - 1];
+                if (c < D[j]) { D[j] = c; K[j] = k; }
+            }
+        }
+        const float sx = b.hi[0] - b.lo[0], sy = b.hi[1] - b.lo[1], sz = b.hi[2] - b.lo[2];
+        const float area = ((sx * sy) + (sy * sz) + (sx * sz)) * 2.0f;
+        const uint32_t cnt = (uint32_t)b.pad1;
+        W8Cost o;
+        uint32_t used = 1u;
+        unsigned long long pl = 0ULL;
+        o.c[0] = cnt <= RT_LEAF_MAX ? area * (float)cnt : (area * (float)(RT_W8_DP_CNODE)) + D[8];
+        for (uint32_t j = 2; j <= 8; j++) pl |= (unsigned long long)K[j] << (3u * (j - 2u));
+        for (uint32_t k = 2; k <= 7; k++) {
+            if (D[k] < o.c[k - 2]) { o.c[k - 1] = D[k]; used = k; } else o.c[k - 1] = o.c[k - 2];
+            pl |= (unsigned long long)(used - 1u) << (21u + 3u * (k - 2u));
+        }
+        cost[p] = o; plan[p] = pl;
+        node = p;
+    }
+}
+
+// The up to eight slots of the wide node that stands for `item`: by the plan where the item is an inner node of the reference
+// tree (its eight slots are shared out between its children as the plan says, down to the nodes that take one slot), else --
+// long leaves, parts of them, scenes of a few triangles -- by the greedy cuts alone.  Slots that the plan leaves free go to
+// cuts of leaf slots that save something.  Both passes of a level call this and must decide alike: it reads only the tree,
+// the triangles and the plan.
+__device__ int w8_gather(const DNode2* __restrict__ n2, const DTri* __restrict__ tris, const unsigned long long* __restrict__ plan,
+                         const W8Item& item, W8Slot* s) {
+    if (RT_W8_DP && plan && item.bnode >= 0 && item.count > RT_LEAF_MAX) {
+        const DNode2 b = n2[item.bnode];
+        if (b.left >= 0 && b.right >= 0) {
+            int32_t todo_node[8]; uint32_t todo_slots[8];
+            int sp = 0, ns = 0;
+            const uint32_t k8 = w8_plan_left(plan[item.bnode], 8u);
+            todo_node[sp] = b.right; todo_slots[sp++] = 8u - k8;
+            todo_node[sp] = b.left; todo_slots[sp++] = k8;
+            while (sp > 0) {
+                const int32_t node = todo_node[--sp];
+                const uint32_t budget = todo_slots[sp];
+                const DNode2 c = n2[node];
+                uint32_t used = 1u;
+                unsigned long long pl = 0ULL;
+                if (budget >= 2u && c.left >= 0 && c.right >= 0) { pl = plan[node]; used = w8_plan_used(pl, budget); }
+                if (used < 2u) { s[ns++] = w8_slot_of_node(n2, tris, node); continue; }
+                const uint32_t k = w8_plan_left(pl, used);
+                todo_node[sp] = c.right; todo_slots[sp++] = used - k;
+                todo_node[sp] = c.left; todo_slots[sp++] = k;
+            }
+            return w8_greedy(n2, tris, s, ns, false);
+        }
+    }
+    int ns = 1;
+    s[0].bnode = item.bnode; s[0].first = item.first; s[0].count = item.count;
+    for (int a = 0; a < 3; a++) { s[0].lo[a] = -RT_INF; s[0].hi[a] = RT_INF; }   // the item itself is always opened first
+    if (item.count <= RT_LEAF_MAX) s[0] = w8_slot_of_range(tris, item.first, item.count);   // a scene of 1-3 triangles
+    return w8_greedy(n2, tris, s, ns, true);
+}
+
 // pass 1 of a level: children that become wide nodes of the next level, and leaf triangles, per wide node
-__global__ void k8_count(uint32_t n_items, const DNode2* __restrict__ n2, const DTri* __restrict__ tris, const W8Item* __restrict__ items,
-                         uint32_t* __restrict__ cnt_inner, uint32_t* __restrict__ cnt_tris) {
+__global__ void k8_count(uint32_t n_items, const DNode2* __restrict__ n2, const DTri* __restrict__ tris, const unsigned long long* __restrict__ plan,
+                         const W8Item* __restrict__ items, uint32_t* __restrict__ cnt_inner, uint32_t* __restrict__ cnt_tris) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n_items) return;
     if (i == n_items) { cnt_inner[i] = 0u; cnt_tris[i] = 0u; return; }   // the scans' extra entry: its exclusive sum is the level's total
     W8Slot s[8];
-    const int ns = w8_gather(n2, tris, items[i], s);
+    const int ns = w8_gather(n2, tris, plan, items[i], s);
     uint32_t ci = 0, ct = 0;
     for (int k = 0; k < ns; k++) {
         if (s[k].count <= RT_LEAF_MAX) ct += s[k].count; else ci++;
@@ -135,13 +241,13 @@ __global__ void k8_count(uint32_t n_items, const DNode2* __restrict__ n2, const 
 // level's stretch of trisw.  The grid arithmetic is done in double: a plane that lands a rounding error (2^-52 of the
 // node's extent) inside the box it should contain is covered many times over by the walk's slack (2^-17 of the scene's extent).
 __global__ void k8_emit(uint32_t n_items, uint32_t level_base, uint32_t next_base, uint32_t tri_level_base, const DNode2* __restrict__ n2,
-                        const DTri* __restrict__ tris, const W8Item* __restrict__ items, const uint32_t* __restrict__ scan_inner,
+                        const DTri* __restrict__ tris, const unsigned long long* __restrict__ plan, const W8Item* __restrict__ items, const uint32_t* __restrict__ scan_inner,
                         const uint32_t* __restrict__ scan_tris, DNode8* __restrict__ out, W8Item* __restrict__ next_items, DTri* __restrict__ trisw,
                         uint32_t* __restrict__ shape /* per node: inner children | leaf slots << 8 */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_items) return;
     W8Slot s[8];
-    const int ns = w8_gather(n2, tris, items[i], s);
+    const int ns = w8_gather(n2, tris, plan, items[i], s);
     float nlo[3] = { RT_INF, RT_INF, RT_INF }, nhi[3] = { -RT_INF, -RT_INF, -RT_INF };
     for (int k = 0; k < ns; k++)
         for (int a = 0; a < 3; a++) { nlo[a] = fminf(nlo[a], s[k].lo[a]); nhi[a] = fmaxf(nhi[a], s[k].hi[a]); }
@@ -318,6 +424,17 @@ int rt_build_walk_tree(rt_scene* s) {
     size_t scan_bytes = 0;
     RT_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, cnt_inner, scan_inner, (int)cap + 1));
     char* scan_tmp; RT_HIP(tmp.alloc(&scan_tmp, scan_bytes));
+    // the collapse plan (temporary: the level loop below reads it, the walk never does)
+    unsigned long long* plan = nullptr;
+    if (RT_W8_DP) {
+        int32_t* parent; uint32_t* arrive; W8Cost* cost;
+        RT_HIP(tmp.alloc(&parent, nn2)); RT_HIP(tmp.alloc(&arrive, nn2)); RT_HIP(tmp.alloc(&cost, nn2)); RT_HIP(tmp.alloc(&plan, nn2));
+        RT_HIP(hipMemset(arrive, 0, sizeof(uint32_t) * (size_t)nn2));
+        RT_HIP(hipMemset(plan, 0, sizeof(unsigned long long) * (size_t)nn2));
+        hipLaunchKernelGGL(k8_parents, dim3((nn2 + T - 1) / T), dim3(T), 0, 0, nn2, d.nodes2, parent);
+        hipLaunchKernelGGL(k8_plan, dim3((nn2 + T - 1) / T), dim3(T), 0, 0, nn2, d.nodes2, d.tris, parent, arrive, cost, plan);
+        RT_HIP(hipGetLastError());
+    }
     const W8Item root{ 0, 0u, nt };   // level 0: the wide node that stands for the reference tree's root
     RT_HIP(hipMemcpy(items[0], &root, sizeof(root), hipMemcpyHostToDevice));
     std::vector<std::pair<uint32_t, uint32_t>> level_of;   // (first node, nodes) per level
@@ -325,7 +442,7 @@ int rt_build_walk_tree(rt_scene* s) {
     int wc = 0;
     while (n_items > 0) {
         if ((size_t)level_base + n_items > cap) { rt_set_error("rt_scene_create: 8-wide tree bookkeeping overflow"); return RT_ERR_DEVICE; }
-        hipLaunchKernelGGL(k8_count, dim3((n_items + 1 + T - 1) / T), dim3(T), 0, 0, n_items, d.nodes2, d.tris, items[wc], cnt_inner, cnt_tris);
+        hipLaunchKernelGGL(k8_count, dim3((n_items + 1 + T - 1) / T), dim3(T), 0, 0, n_items, d.nodes2, d.tris, plan, items[wc], cnt_inner, cnt_tris);
         RT_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, cnt_inner, scan_inner, (int)n_items + 1));
         RT_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, cnt_tris, scan_tris, (int)n_items + 1));
         uint32_t n_next = 0, n_level_tris = 0;
@@ -333,7 +450,7 @@ int rt_build_walk_tree(rt_scene* s) {
         RT_HIP(hipMemcpy(&n_level_tris, scan_tris + n_items, sizeof(uint32_t), hipMemcpyDeviceToHost));
         const uint32_t next_base = level_base + n_items;
         if ((size_t)next_base + n_next > cap || (size_t)tri_total + n_level_tris > nt) { rt_set_error("rt_scene_create: 8-wide tree bookkeeping overflow"); return RT_ERR_DEVICE; }
-        hipLaunchKernelGGL(k8_emit, dim3((n_items + T - 1) / T), dim3(T), 0, 0, n_items, level_base, next_base, tri_total, d.nodes2, d.tris, items[wc],
+        hipLaunchKernelGGL(k8_emit, dim3((n_items + T - 1) / T), dim3(T), 0, 0, n_items, level_base, next_base, tri_total, d.nodes2, d.tris, plan, items[wc],
                            scan_inner, scan_tris, wide, items[wc ^ 1], (DTri*)p_trisw, shape);
         RT_HIP(hipGetLastError());
         level_of.emplace_back(level_base, n_items);
