@@ -13,6 +13,9 @@
 #ifndef RT_TRAV_WAVES
 #define RT_TRAV_WAVES 5    // __launch_bounds__ waves/SIMD target of the traversal kernels (96 VGPRs: the 8-wide node step spills at 80; 4 waves: -5 %)
 #endif
+#ifndef RT_NODE_MIX
+#define RT_NODE_MIX 1      // the node step's plane bytes through v_perm_b32 + v_fma_mix_f32 (0: v_bfi + v_cvt_f32_ubyte + v_fma_f32, the same bits)
+#endif
 #ifndef RT_STACK_LDS
 #define RT_STACK_LDS 12          // 8-byte stack entries per lane kept in LDS (24 KB per 256-thread block)
 #endif
@@ -78,6 +81,7 @@ __device__ __host__ __forceinline__ float rt_rng_next(Rng& r) {
 // An entry is a group of the 8-wide walk (rt_node_eval): {child_base, hit bits << 24 | imask} -- the children of one node
 // that still have to be entered -- or {tri_base, triangle bits} -- the triangles of one node that still have to be tested.
 typedef uint32_t rt_u2 __attribute__((ext_vector_type(2)));
+typedef _Float16 rt_h2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) rt_u2 rt_lds_u2;  // explicit LDS address space: keeps pops ds_read, not flat_load
 #define RT_STACK_WORDS (2 * RT_STACK_LDS * RT_BLOCK)
 #define RT_SPILL_WORDS(walk_stack) ((walk_stack) > (uint32_t)RT_STACK_LDS ? ((walk_stack) - (uint32_t)RT_STACK_LDS) * 2u : 0u)   // per lane
@@ -156,6 +160,17 @@ __device__ __forceinline__ bool rt_box_exact(f3 lo, f3 hi, f3 o, f3 inv, float& 
 // NaN, v_min/v_max agree with the reference's ternaries, and box containment implies test monotonicity.
 __device__ __forceinline__ bool rt_ray_is_tame(f3 inv) {
     return (fabsf(inv.x) < 1e18f) && (fabsf(inv.y) < 1e18f) && (fabsf(inv.z) < 1e18f);
+}
+// With RT_NODE_MIX a node step multiplies 1/dir by the node's grid step * 2^24 (rt_node_eval: the plane bytes are read as f16
+// denormals).  A grid step is at most 8/255 of the scene's largest coordinate (k8_emit, walk_tree.hip), so below this bound the
+// scaled factor stays finite (< 5.3e36); a ray above it -- |1/dir| of 1e18 in a scene of 1e13 -- takes the exact walk.  False if
+// the product is inf or NaN.
+__device__ __forceinline__ bool rt_ray_fits_grid(const DScene& S, f3 inv) {
+#if RT_NODE_MIX
+    return fmaxf(fabsf(inv.x), fmaxf(fabsf(inv.y), fabsf(inv.z))) * S.abs_max < 1e31f;
+#else
+    return true;
+#endif
 }
 // Beyond that there are rays no renderer shoots but a caller can pass: NaN / inf / 1e38 in the origin or the direction.  Their
 // slab products overflow or are NaN in ways the padded culling was not derived for (it assumes finite arithmetic), so they
@@ -313,7 +328,7 @@ struct Walk {
     uint32_t pb, pm;   // pend
     uint32_t sp, sb;   // the stack holds entries [sb, sp): pushes and pops at sp; the tail's work stealing takes from sb, the oldest entry (the largest subtree the walk has waiting)
     uint32_t q4;       // the ray's octant (bit a set where dir is non-negative on axis a) in each of the four bytes
-    uint32_t mx, my, mz;   // all ones where 1/dir is negative on that axis, else 0: picks a node's hi planes as the near planes
+    uint32_t mx, my, mz;   // which of a node's lo / hi planes are the near ones on that axis, by the sign of 1/dir: a v_perm_b32 byte selector (RT_NODE_MIX) or an all-ones / zero mask
     bool occluded;
     bool wide;         // this item went through the wide walk: its answer still has to pass rt_settle
 };
@@ -321,7 +336,13 @@ __device__ __forceinline__ bool rt_cur_is_nodes(const Walk& w) { return (w.cm >>
 __device__ __forceinline__ bool rt_cur_is_tris(const Walk& w) { return w.cm != 0u && (w.cm >> 24) == 0u; }
 __device__ __forceinline__ bool rt_walk_done(const Walk& w) { return w.cm == 0u && w.pm == 0u; }
 __device__ __forceinline__ void rt_walk_signs(Walk& w) {
+#if RT_NODE_MIX
+    // byte selectors of v_perm_b32 {S0 = the node's hi planes, S1 = its lo planes}: bytes 0 and 2 of the near planes' word into
+    // the low bytes of the two 16-bit halves, zeros above them (0x0c); bytes 4-7 name S0, i.e. hi is near where 1/dir < 0
+    w.mx = w.inv.x < 0.0f ? 0x0c060c04u : 0x0c020c00u; w.my = w.inv.y < 0.0f ? 0x0c060c04u : 0x0c020c00u; w.mz = w.inv.z < 0.0f ? 0x0c060c04u : 0x0c020c00u;
+#else
     w.mx = w.inv.x < 0.0f ? 0xFFFFFFFFu : 0u; w.my = w.inv.y < 0.0f ? 0xFFFFFFFFu : 0u; w.mz = w.inv.z < 0.0f ? 0xFFFFFFFFu : 0u;
+#endif
     w.q4 = ((w.inv.x < 0.0f ? 0u : 1u) | (w.inv.y < 0.0f ? 0u : 2u) | (w.inv.z < 0.0f ? 0u : 4u)) * 0x01010101u;
 }
 __device__ __forceinline__ void rt_walk_init(const DScene& S, Walk& w, f3 o, f3 dir, f3 inv, float maxT) {
@@ -373,13 +394,54 @@ __device__ __forceinline__ void rt_node_eval(const DScene& S, Walk& w, TravStack
     const uint4 r3 = *reinterpret_cast<const uint4*>(nb + (base + 48u));   // loz[2] hix[2]
     const uint4 r4 = *reinterpret_cast<const uint4*>(nb + (base + 64u));   // hiy[2] hiz[2]
     const uint32_t hw = __float_as_uint(r0.w);
+#if RT_NODE_MIX
+    // the plane bytes are read as f16 denormals (0x00qq = q * 2^-24, exactly), so the step carries the 2^24: A = ldexp(inv, e + 24)
+    const float ax = ldexpf(w.inv.x, ((int)(hw << 24) >> 24) + 24), ay = ldexpf(w.inv.y, ((int)(hw << 16) >> 24) + 24), az = ldexpf(w.inv.z, ((int)(hw << 8) >> 24) + 24);
+#else
     const float ax = ldexpf(w.inv.x, (int)(hw << 24) >> 24), ay = ldexpf(w.inv.y, (int)(hw << 16) >> 24), az = ldexpf(w.inv.z, (int)(hw << 8) >> 24);
+#endif
     const float dx = r0.x - w.o.x, dy = r0.y - w.o.y, dz = r0.z - w.o.z;
     const float blx = __builtin_fmaf(dx, w.inv.x, -w.pad.x), bhx = __builtin_fmaf(dx, w.inv.x, w.pad.x);
     const float bly = __builtin_fmaf(dy, w.inv.y, -w.pad.y), bhy = __builtin_fmaf(dy, w.inv.y, w.pad.y);
     const float blz = __builtin_fmaf(dz, w.inv.z, -w.pad.z), bhz = __builtin_fmaf(dz, w.inv.z, w.pad.z);
     const float limit = ANY ? w.maxT : w.best.t;
     uint32_t hit = 0u;
+#if RT_NODE_MIX
+    // Four slots per pass.  Near / far plane bytes by the ray's sign AND their conversion in one go: v_perm_b32 puts bytes 0 and 2
+    // (then 1 and 3) of the near word into the low bytes of the two halves of a register, where they read as f16 denormals, and
+    // v_fma_mix_f32 takes a half as its first operand -- q * 2^-24 * (A * 2^24) + B is the same product, rounded once, as
+    // v_cvt_f32_ubyte + v_fma_f32 gave: 24 v_perm + 48 v_fma_mix per node where 12 v_bfi + 48 v_cvt + 48 v_fma stood, bit-identical.
+    const uint32_t sx1 = w.mx + 0x00010001u, sy1 = w.my + 0x00010001u, sz1 = w.mz + 0x00010001u;
+#define RT_HX(v) ((float)__builtin_bit_cast(rt_h2, v).x)
+#define RT_HY(v) ((float)__builtin_bit_cast(rt_h2, v).y)
+#define RT_SLOT(H, P, SH)                                                                                                     \
+    {                                                                                                                         \
+        const float lo_ = fmaxf(__builtin_fmaf(H(nx##P), ax, blx), fmaxf(__builtin_fmaf(H(ny##P), ay, bly), __builtin_fmaf(H(nz##P), az, blz))); \
+        const float hi_ = fminf(__builtin_fmaf(H(fx##P), ax, bhx), fminf(__builtin_fmaf(H(fy##P), ay, bhy), __builtin_fmaf(H(fz##P), az, bhz))); \
+        const bool pass = fmaxf(lo_, 0.0f) <= fminf(hi_, limit);                                                               \
+        const uint32_t b_ = ((bits >> SH) & 255u) << ((idx >> SH) & 255u);                                                    \
+        hit |= pass ? b_ : 0u;                                                                                                \
+    }
+#define RT_HALF(LOX, LOY, LOZ, HIX, HIY, HIZ, META)                                                                           \
+    {                                                                                                                         \
+        const uint32_t nxa = __builtin_amdgcn_perm(HIX, LOX, w.mx), nxb = __builtin_amdgcn_perm(HIX, LOX, sx1);               \
+        const uint32_t fxa = __builtin_amdgcn_perm(LOX, HIX, w.mx), fxb = __builtin_amdgcn_perm(LOX, HIX, sx1);               \
+        const uint32_t nya = __builtin_amdgcn_perm(HIY, LOY, w.my), nyb = __builtin_amdgcn_perm(HIY, LOY, sy1);               \
+        const uint32_t fya = __builtin_amdgcn_perm(LOY, HIY, w.my), fyb = __builtin_amdgcn_perm(LOY, HIY, sy1);               \
+        const uint32_t nza = __builtin_amdgcn_perm(HIZ, LOZ, w.mz), nzb = __builtin_amdgcn_perm(HIZ, LOZ, sz1);               \
+        const uint32_t fza = __builtin_amdgcn_perm(LOZ, HIZ, w.mz), fzb = __builtin_amdgcn_perm(LOZ, HIZ, sz1);               \
+        const uint32_t inner = ((META & (META << 1)) & 0x10101010u) >> 4;   /* 1 in the bytes of inner children (index 24-31) */ \
+        const uint32_t idx = (META ^ ((inner * 7u) & w.q4)) & 0x1F1F1F1Fu;  /* their index XOR the ray's octant */              \
+        const uint32_t bits = (META >> 5) & 0x07070707u;                                                                      \
+        RT_SLOT(RT_HX, a, 0) RT_SLOT(RT_HX, b, 8) RT_SLOT(RT_HY, a, 16) RT_SLOT(RT_HY, b, 24)                                 \
+    }
+    RT_HALF(r2.x, r2.z, r3.x, r3.z, r4.x, r4.z, r1.z)
+    RT_HALF(r2.y, r2.w, r3.y, r3.w, r4.y, r4.w, r1.w)
+#undef RT_HALF
+#undef RT_SLOT
+#undef RT_HX
+#undef RT_HY
+#else
     // four slots per pass: the near / far plane bytes by the ray's sign, and per slot the bits it stands for and where they go
 #define RT_SLOT(UB, SH)                                                                                                       \
     {                                                                                                                         \
@@ -403,6 +465,7 @@ __device__ __forceinline__ void rt_node_eval(const DScene& S, Walk& w, TravStack
     RT_HALF(r2.y, r2.w, r3.y, r3.w, r4.y, r4.w, r1.w)
 #undef RT_HALF
 #undef RT_SLOT
+#endif
     const uint32_t gm = hit & 0xFF000000u, tm = hit & 0x00FFFFFFu;
     const bool pend_free = w.pm == 0u;
     w.pb = pend_free ? r1.y : w.pb; w.pm = pend_free ? tm : w.pm;
@@ -504,7 +567,7 @@ __device__ __forceinline__ bool rt_closest_begin(const DScene& S, f3 o, f3 dir, 
     if (mode == 0 && dir.x == 0.0f && dir.y == 0.0f && dir.z == 0.0f) return true;
     f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
     const bool moderate = rt_ray_is_moderate(o, dir);
-    if (mode == 0 && moderate && rt_ray_is_tame(inv)) { rt_walk_init(S, w, o, dir, inv, 0.0f); return false; }
+    if (mode == 0 && moderate && rt_ray_is_tame(inv) && rt_ray_fits_grid(S, inv)) { rt_walk_init(S, w, o, dir, inv, 0.0f); return false; }
     if (COUNT) cexact++;
     if (mode == 0 && moderate) rt_walk_exact<false, COUNT>(S, o, dir, 0.0f, w.best, spill2, gstride, cn, ct);
     else rt_walk_reference<false, COUNT>(S, o, dir, 0.0f, w.best, spill2, gstride, cn, ct);
@@ -523,7 +586,7 @@ __device__ __forceinline__ bool rt_visible_begin(const DScene& S, f3 p1, f3 p2, 
     if (S.root_ref == RT_REF_EMPTY) return true;
     f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
     const bool moderate = rt_ray_is_moderate(o, dir);
-    if (mode == 0 && moderate && rt_ray_is_tame(inv)) { rt_walk_init(S, w, o, dir, inv, maxT); return false; }
+    if (mode == 0 && moderate && rt_ray_is_tame(inv) && rt_ray_fits_grid(S, inv)) { rt_walk_init(S, w, o, dir, inv, maxT); return false; }
     if (COUNT) cexact++;
     HitRec dummy;
     visible = (mode == 0 && moderate) ? rt_walk_exact<true, COUNT>(S, o, dir, maxT, dummy, spill2, gstride, cn, ct)
