@@ -23,6 +23,8 @@
 #define RT_PAD_SCALE_EXACT 6.103515625e-05f   // 2^-14: cull slack of rt_walk_exact (the wide walk's is RT_PAD_SCALE, 2^-17)
 #define RT_INF __builtin_inff()
 
+// the wave's lane mask of a predicate, straight from its compare (HIP's __ballot goes through an int: v_cndmask + v_cmp per call)
+__device__ __forceinline__ unsigned long long rt_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 struct f3 { float x, y, z; };
 __device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 v; v.x = x; v.y = y; v.z = z; return v; }
 __device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
@@ -473,7 +475,7 @@ __device__ __forceinline__ void rt_node_eval(const DScene& S, Walk& w, TravStack
     const bool x2 = tm != 0u && !pend_free;      // triangles that have to wait for pend
     const bool x3 = rem >= (1u << 24);           // the old cur has children left
     const bool push_rem = x3 && (x1 || x2), push_tri = x2 && x1;
-    if (__ballot(w.sp + 2u > (uint32_t)RT_STACK_LDS) == 0) {
+    if (rt_ballot(w.sp + 2u > (uint32_t)RT_STACK_LDS) == 0) {
         // every lane has room in LDS for two more: store unconditionally, advance by the predicate
         rt_u2 v; v.x = w.cb; v.y = rem;
         st.lds[w.sp * RT_BLOCK] = v; w.sp += push_rem ? 1u : 0u;
@@ -498,7 +500,7 @@ __device__ __forceinline__ bool rt_tri_eval_step(const DScene& S, Walk& w, TravS
     float t, u, v;
     if (rt_tri_eval_all(a, b, c, e, w.o, w.dir, t, u, v)) {
         const uint32_t rank = __float_as_uint(e.z);   // trisw keeps the DFS rank where tris keeps orig_id
-        if (ANY) { if (t < w.maxT) { w.occluded = true; w.best.rank = rank; return true; } }
+        if (ANY) { if (t < w.maxT) { w.occluded = true; w.best.rank = rank; w.cm = 0u; w.pm = 0u; return true; } }   // cm, pm: see rt_vote_step
         else if (t < w.best.t || (t == w.best.t && rank < w.best.rank)) { w.best.t = t; w.best.u = u; w.best.v = v; w.best.rank = rank; }
     }
     if (w.pm == 0u && rt_cur_is_tris(w)) { w.pb = w.cb; w.pm = w.cm; rt_pop<ANY>(w, st); }
@@ -528,10 +530,14 @@ __device__ __forceinline__ bool rt_wide_step(const DScene& S, Walk& w, TravStack
 #endif
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ bool rt_vote_step(const DScene& S, Walk& w, bool busy, TravStack& st, uint32_t& c_nodes, uint32_t& c_tris) {
-    const bool innode = busy && rt_cur_is_nodes(w);
-    const bool inleaf = busy && w.pm != 0u;
-    const uint32_t nl = (uint32_t)__popcll(__ballot(inleaf)), nn = (uint32_t)__popcll(__ballot(innode));
-    if (nn * (uint32_t)RT_VOTE_NUM >= nl * (uint32_t)RT_VOTE_DEN) {
+    // a lane without a walk holds cm == 0 and pm == 0 (rt_persistent_walk clears them at the start, a walk leaves them so
+    // when it ends, and the two early exits -- an any-hit blocker, a part cut short in the tail -- clear them), so the two
+    // ballots come straight from compares on the state: `busy &&` cost an s_and, a v_cndmask and a second v_cmp per ballot
+    (void)busy;
+    const bool innode = rt_cur_is_nodes(w);
+    const bool inleaf = w.pm != 0u;
+    const int nl = __builtin_popcountll(rt_ballot(inleaf)), nn = __builtin_popcountll(rt_ballot(innode));
+    if (nn * RT_VOTE_NUM >= nl * RT_VOTE_DEN) {
 #ifdef RT_DBG_WAVESTEPS
         if (COUNT) c_nodes++;
 #endif
@@ -663,13 +669,13 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
     const uint32_t lane = threadIdx.x & 63;
     uint32_t c_slots = 0, c_busy = 0, c_mine = 0, c_max = 0, c_refused = 0;
     Walk w;
-    w.wide = false;
+    w.wide = false; w.cm = 0u; w.pm = 0u;
     uint32_t item = 0;
     bool busy = false, done = false, visible = true;
     uint32_t pb = 0, pe = 0;   // the wave's pool of granted items (wave-uniform)
     bool drained = false;      // wave-uniform
     for (;;) {
-        unsigned long long idle = __ballot(!busy);
+        unsigned long long idle = rt_ballot(!busy);
         uint32_t nidle = (uint32_t)__popcll(idle);
         if (drained ? (nidle == 64u) : (nidle >= (uint32_t)(ANY ? RT_REFILL_IDLE_ANY : RT_REFILL_IDLE))) {
             if (done) { rt_settle<ANY, COUNT>(S, w, visible, spill2, gstride, cn, ct, c_refused); job.retire(item, w, visible); done = false; }
@@ -716,13 +722,13 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
         uint32_t own = lane;
         tail_key[threadIdx.x] = ~0ULL; tail_parts[threadIdx.x] = busy ? 1u : 0u; tail_item[threadIdx.x] = item;
         for (uint32_t round = 0;; round++) {
-            if (!__ballot(busy)) break;
+            if (!rt_ballot(busy)) break;
             bool ended = false;
             if ((round % (uint32_t)RT_STEAL_EVERY) == 0u) {
                 // any hit: a blocker found by one part ends the others
-                if (ANY && busy && *(volatile unsigned long long*)&tail_key[wbase + own] != ~0ULL) ended = true;
-                const unsigned long long fm = __ballot(!busy);                          // free: no walk
-                const unsigned long long dm = __ballot(busy && !ended && w.sp > w.sb);  // donors: a subtree waiting on the stack
+                if (ANY && busy && *(volatile unsigned long long*)&tail_key[wbase + own] != ~0ULL) { ended = true; w.cm = 0u; w.pm = 0u; }
+                const unsigned long long fm = rt_ballot(!busy);                          // free: no walk
+                const unsigned long long dm = rt_ballot(busy && !ended && w.sp > w.sb);  // donors: a subtree waiting on the stack
                 uint32_t n = (uint32_t)__popcll(fm), nd = (uint32_t)__popcll(dm);
                 n = n < nd ? n : nd;
                 if (n) {
