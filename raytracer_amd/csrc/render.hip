@@ -1125,6 +1125,7 @@ struct GatherJob {
         Shading sd; f3 vx, vn, wi; float G; float4 r0, r3; col3 T; uint32_t path, v;
         if (!terms(k, sd, vx, vn, wi, G, r0, r3, T, path, v)) return;
         sd.frame = frame_from(sd.sN);
+        sd.albedo = tex_sample(S, S.mats[sd.mat].tex, sd.tu, sd.tv);
         col3 fx = bsdf_eval(S, sd, wi);
         col3 Le = mkc(r3.x, r3.y, r3.z), term;
         int vmat = __float_as_int(r0.w);
@@ -1135,6 +1136,7 @@ struct GatherJob {
             Shading vs;
             vs.x = vx; vs.sN = vn; vs.gN = vn; vs.wo = mk3(r2.x, r2.y, r2.z); vs.tu = r1.w; vs.tv = r2.w; vs.mat = (uint32_t)vmat;
             vs.frame = frame_from(vn);
+            vs.albedo = tex_sample(S, S.mats[vs.mat].tex, vs.tu, vs.tv);
             col3 fxi = bsdf_eval(S, vs, -wi);
             term = ((fx * G) * fxi) * Le;
         }
@@ -1170,6 +1172,7 @@ __global__ void k_debug_bsdf(DScene S, uint32_t mat, const float* wo, const floa
     sd.tu = uv[i * 2]; sd.tv = uv[i * 2 + 1]; sd.mat = mat;
     if ((S.mats[mat].flags & RT_MF_TWOSIDED) && dot3(sd.wo, sd.sN) < 0) { sd.sN = -sd.sN; sd.gN = sd.sN; }
     sd.frame = frame_from(sd.sN);
+    sd.albedo = tex_sample(S, S.mats[mat].tex, sd.tu, sd.tv);
     if (do_sample) {
         Rng rng; rng.key = kc[i * 2]; rng.ctr = kc[i * 2 + 1];
         col3 f; float pdf;

@@ -30,6 +30,7 @@ struct Shading {   // ShadingData (Materials.h:14)
     float tu, tv;
     Frame3 frame;
     uint32_t mat;
+    col3 albedo;   // Texture::sample of the material's texture at (tu, tv): every BSDF reads it, evaluate() and sample() alike (Materials.h), so it is fetched once per shading point (shading_albedo)
 };
 
 // ---- Texture::sample (Imaging.h:71-93)
@@ -130,7 +131,7 @@ __device__ inline col3 bsdf_eval(const DScene& S, const Shading& sd, f3 wi) {
     switch (m.type) {
     case RT_MAT_DIFFUSE:
     case RT_MAT_ORENNAYAR:  // Materials.h:777 returns Lambert before the Oren-Nayar terms
-        return tex_sample(S, m.tex, sd.tu, sd.tv) / (float)RT_PI;
+        return sd.albedo / (float)RT_PI;
     case RT_MAT_MIRROR: case RT_MAT_GLASS:
         return mkc(0, 0, 0);
     case RT_MAT_CONDUCTOR: {  // Materials.h:360
@@ -142,7 +143,7 @@ __device__ inline col3 bsdf_eval(const DScene& S, const Shading& sd, f3 wi) {
         float D = d_ggx(wm, m.alpha), G = g_ggx(wl, wo, m.alpha);
         col3 F = fresnel_conductor(dot3(wo, wm), mkc(m.eta[0], m.eta[1], m.eta[2]), mkc(m.k[0], m.k[1], m.k[2]));
         col3 brdf = ((F * D) * G) / (4.0f * wo.z * wl.z);
-        return tex_sample(S, m.tex, sd.tu, sd.tv) * brdf;
+        return sd.albedo * brdf;
     }
     case RT_MAT_DIELECTRIC: {  // Materials.h:638
         f3 wo = to_local(sd.frame, sd.wo), wl = to_local(sd.frame, wi);
@@ -162,7 +163,7 @@ __device__ inline col3 bsdf_eval(const DScene& S, const Shading& sd, f3 wi) {
             float den = ri * dot3(wl, wm) + dot3(wo, wm);
             result = (1 - F) * D * G * dot3(wl, wm) * dot3(wo, wm) / (powf(den, 2) * wl.z * wo.z);
         }
-        return tex_sample(S, m.tex, sd.tu, sd.tv) * result;
+        return sd.albedo * result;
     }
     case RT_MAT_PLASTIC: {  // Materials.h:931
         f3 wo = to_local(sd.frame, sd.wo), wl = to_local(sd.frame, wi);
@@ -170,7 +171,7 @@ __device__ inline col3 bsdf_eval(const DScene& S, const Shading& sd, f3 wi) {
         float iorT, iorI; set_ior(wo.z, iorI, iorT, m.int_ior, m.ext_ior);
         float ks = fresnel_dielectric(wo.z, iorI, iorT), kd = 1.0f - ks;
         float e = m.phong_e;
-        col3 diffuse = (tex_sample(S, m.tex, sd.tu, sd.tv) * kd) / (float)RT_PI;
+        col3 diffuse = (sd.albedo * kd) / (float)RT_PI;
         f3 wr = mk3(-wo.x, -wo.y, wo.z);
         float cosAlpha = smaxf(0.0f, dot3(wr, wl));
         float gloss = (float)(ks * ((e + 2) / (2 * RT_PI)) * powf(cosAlpha, e));
@@ -231,7 +232,7 @@ __device__ inline f3 bsdf_sample(const DScene& S, const Shading& sd, Rng& rng, c
         float r1 = rt_rng_next(rng), r2 = rt_rng_next(rng);
         f3 wi = cosine_sample_hemisphere(r1, r2);
         pdf = (float)(wi.z / RT_PI);
-        f = tex_sample(S, m.tex, sd.tu, sd.tv) / (float)RT_PI;
+        f = sd.albedo / (float)RT_PI;
         return to_world(sd.frame, wi);
     }
     case RT_MAT_ORENNAYAR: {  // Materials.h:759
@@ -246,7 +247,7 @@ __device__ inline f3 bsdf_sample(const DScene& S, const Shading& sd, Rng& rng, c
         f3 wo = to_local(sd.frame, sd.wo);
         f3 wi = mk3(-wo.x, -wo.y, wo.z);
         pdf = 1.0f;
-        f = tex_sample(S, m.tex, sd.tu, sd.tv) / wi.z;
+        f = sd.albedo / wi.z;
         return to_world(sd.frame, wi);
     }
     case RT_MAT_CONDUCTOR: {  // Materials.h:309
@@ -256,7 +257,7 @@ __device__ inline f3 bsdf_sample(const DScene& S, const Shading& sd, Rng& rng, c
         if (m.alpha < 0.001f) {
             f3 wi = mk3(-wo.x, -wo.y, wo.z);
             pdf = 1.0f;
-            f = tex_sample(S, m.tex, sd.tu, sd.tv) * fresnel_conductor(wi.z, eta, kk);
+            f = sd.albedo * fresnel_conductor(wi.z, eta, kk);
             return to_world(sd.frame, wi);
         }
         float r1 = rt_rng_next(rng), r2 = rt_rng_next(rng);
@@ -270,7 +271,7 @@ __device__ inline f3 bsdf_sample(const DScene& S, const Shading& sd, Rng& rng, c
         col3 F = fresnel_conductor(dot3(wl, wm), eta, kk);
         col3 brdf = ((F * D) * G) / (4.0f * wo.z * wl.z);
         pdf = D * wm.z / (4 * dot3(wo, wm));
-        f = ((tex_sample(S, m.tex, sd.tu, sd.tv) * brdf) * fabsf(wl.z)) / pdf;
+        f = ((sd.albedo * brdf) * fabsf(wl.z)) / pdf;
         return to_world(sd.frame, wl);
     }
     case RT_MAT_GLASS: {  // Materials.h:447
@@ -283,14 +284,14 @@ __device__ inline f3 bsdf_sample(const DScene& S, const Shading& sd, Rng& rng, c
         bool reflect = rt_rng_next(rng) < F;
         if (reflect) {
             wi = mk3(-wo.x, -wo.y, wo.z);
-            f = tex_sample(S, m.tex, sd.tu, sd.tv);
+            f = sd.albedo;
             pdf = F;
         } else {
             float sinI = sqrtf(smaxf(0.0f, 1.0f - powf(cosTheta, 2)));
             float sinT = ri * sinI;
             if (sinT >= 1.0f) {
                 wi = mk3(-wo.x, -wo.y, wo.z);
-                f = tex_sample(S, m.tex, sd.tu, sd.tv);
+                f = sd.albedo;
                 pdf = 1.0f;
             } else {
                 float cosT = sqrtf(smaxf(0.0f, 1 - powf(sinT, 2)));
@@ -298,7 +299,7 @@ __device__ inline f3 bsdf_sample(const DScene& S, const Shading& sd, Rng& rng, c
                 wi.z = cosTheta > 0 ? -cosT : cosT;
                 wi = norm3(wi);
                 pdf = (1.0f - F);
-                f = tex_sample(S, m.tex, sd.tu, sd.tv) * (pdf * ri * ri);
+                f = sd.albedo * (pdf * ri * ri);
             }
         }
         return to_world(sd.frame, norm3(wi));
@@ -346,11 +347,11 @@ __device__ inline f3 bsdf_sample(const DScene& S, const Shading& sd, Rng& rng, c
         if (reflect) {
             pdf = D * wm.z / (4 * dot3(wo, wm));
             float brdf = F * D * G / (4.0f * wo.z * wl.z);
-            f = ((tex_sample(S, m.tex, sd.tu, sd.tv) * brdf) * fabsf(wl.z)) / pdf;
+            f = ((sd.albedo * brdf) * fabsf(wl.z)) / pdf;
         } else {
             float den = ri * dot3(wl, wm) + dot3(wo, wm);
             float bsdf = ((1 - F) * D * G * dot3(wl, wm) * dot3(wo, wm)) / (powf(den, 2) * wl.z * wo.z);
-            f = ((tex_sample(S, m.tex, sd.tu, sd.tv) * bsdf) * fabsf(wl.z)) / pdf;
+            f = ((sd.albedo * bsdf) * fabsf(wl.z)) / pdf;
         }
         return to_world(sd.frame, wl);
     }
@@ -376,7 +377,7 @@ __device__ inline f3 bsdf_sample(const DScene& S, const Shading& sd, Rng& rng, c
         }
         float cosAlpha = smaxf(0.0f, dot3(wr, wl));
         pdf = (float)((kd * (wl.z / RT_PI)) + (ks * (e + 1) * powf(cosAlpha, e) / (2 * RT_PI)));
-        col3 diffuse = (tex_sample(S, m.tex, sd.tu, sd.tv) * kd) / (float)RT_PI;
+        col3 diffuse = (sd.albedo * kd) / (float)RT_PI;
         float gloss = (float)(ks * ((e + 2) / (2 * RT_PI)) * powf(cosAlpha, e));
         f = diffuse + mkc(gloss, gloss, gloss);
         return to_world(sd.frame, wl);
@@ -509,5 +510,6 @@ __device__ inline Shading shading_data(const DScene& S, f3 o, f3 dir, float t, f
         if (dot3(sd.wo, sd.gN) < 0) sd.gN = -sd.gN;
     }
     sd.frame = frame_from(sd.sN);
+    sd.albedo = tex_sample(S, S.mats[sd.mat].tex, sd.tu, sd.tv);
     return sd;
 }
