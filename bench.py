@@ -246,13 +246,14 @@ def main():
                 "film_mean": film_mean, "film_median": film_median, "film_nonfinite_values": film_nan,
             },
             "roofline": {
-                # what limits the dominant kernel: VALU instruction issue, not HBM or MFMA.  By the PMC counters of this command (profiles/)
-                # VALU issue slots are full with 37 of 64 lanes live per instruction; a cycle model of instructions per step x steps per
-                # ray / lanes served reproduces the kernel's time
+                # what limits the dominant kernel: VALU instruction issue first, latency second, neither HBM nor MFMA.  By the PMC counters of
+                # this command (profiles/) a launch issues 1.29e9 VALU wave-instructions at 4.4 SIMD cycles each against a measured mean issue
+                # cost of ~3.9 (tools/ubench_valu.hip), with 38 of 64 lanes live per instruction
                 "bound": "issue",
                 "bound_is": "VALU instruction issue, neither HBM nor MFMA: cycles per ray = sum over step kinds of (lane-steps per ray / lanes served per wave step) x "
-                            "instructions per step x 4 reproduces the kernel's time (8-wide node step 330 instructions, triangle step 140, 36 / 30 of 64 lanes served); "
-                            "fabric traffic is < 0.25 of the HBM peak",
+                            "instructions per step x issue cost reproduces the kernel's time (8-wide node step 265 VALU + 82 SALU instructions, triangle step 135 + 39; "
+                            "issue cost 4.0-4.3 cycles per wave-instruction, 2.6 for add / mul / logic ops, measured); the issue slots are ~89 % full, the rest is latency "
+                            "that 5 waves per SIMD do not hide; fabric traffic is ~0.26 of the HBM peak",
                 "kernel": "k_extend<false,false,0> (closest-hit walk over the 8-wide quantised tree)",
                 # the SURVEY 8(d) figure: ALGORITHMIC bytes (every 80-B node and 64-B triangle fetch counted, cache hits included)
                 # per launch / average launch duration by HIP events over the timed regions, against the HBM peak
