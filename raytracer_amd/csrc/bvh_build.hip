@@ -298,7 +298,7 @@ __global__ void k_records(uint32_t n, const float* __restrict__ verts, const uin
         DTriShade sh;
         for (int k = 0; k < 3; k++) { sh.n0[k] = f[3 + k]; sh.n1[k] = f[11 + k]; sh.n2[k] = f[19 + k]; }
         sh.uv[0] = f[6]; sh.uv[1] = f[7]; sh.uv[2] = f[14]; sh.uv[3] = f[15]; sh.uv[4] = f[22]; sh.uv[5] = f[23];
-        sh.area = sqrtf((c[0] * c[0]) + (c[1] * c[1]) + (c[2] * c[2])) * 0.5f;
+        sh.mat_gsign = o.mat_gsign;
         shade[r] = sh;
         for (int k = 0; k < 3; k++) {
             lo[k] = fkey(fminf(p0[k], fminf(p1[k], p2[k]))); hi[k] = fkey(fmaxf(p0[k], fmaxf(p1[k], p2[k])));

@@ -417,7 +417,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_OCC) void k_shade(DScene S
                     const TriRows lt = tri_rows(S.tris + light.tri);
                     col3 emitted = mat_emission(S.mats[tri_mat_gsign(lt) & 0x7FFFFFFFu]);
                     f3 p = tri_sample_point(lt, r1, r2);
-                    float pdf = 1 / S.trishade[light.tri].area;
+                    float pdf = 1 / light.area;
                     f3 wi = p - sd.x;
                     float l = lensq3(wi);
                     wi = norm3(wi);
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_aov(DScene S, RBuf R, Ctl* ctl, in
                             const DTri& lt = S.tris[light.tri];
                             col3 emitted = mat_emission(S.mats[lt.mat_gsign & 0x7FFFFFFFu]);
                             f3 p = tri_sample_point(lt, r1, r2);
-                            float pdf = 1 / S.trishade[light.tri].area;
+                            float pdf = 1 / light.area;
                             f3 wi = p - sd.x;
                             float l = lensq3(wi);
                             wi = norm3(wi);
@@ -913,7 +913,7 @@ __device__ inline void light_emit(const DScene& S, Rng& rng, float N_vpl, bool f
     if (light.kind == 0) {
         const DTri& lt = S.tris[light.tri];
         p = tri_sample_point(lt, r1, r2);                              // samplePositionFromLight (Lights.h:66)
-        pdfPos = 1 / S.trishade[light.tri].area;
+        pdfPos = 1 / light.area;
         f3 wl = cosine_sample_hemisphere(r3, r4);                      // sampleDirectionFromLight (Lights.h:70)
         pdfDir = cosine_hemisphere_pdf(wl);
         ln = tri_gnormal(lt);
@@ -1108,7 +1108,7 @@ struct GatherJob {
         G = cx_ * cxi / (dist * dist);
         if (G <= 0.0f) return false;
         const float4 c = e[2], dd = e[3];
-        sd.gN = sd.sN; sd.wo = mk3(c.x, c.y, c.z); sd.tu = b.w; sd.tv = c.w; sd.mat = __float_as_uint(dd.w);
+        sd.wo = mk3(c.x, c.y, c.z); sd.tu = b.w; sd.tv = c.w; sd.mat = __float_as_uint(dd.w);
         T = mkc(dd.x, dd.y, dd.z);
         path = __float_as_uint(a.w);
         return true;
@@ -1134,7 +1134,7 @@ struct GatherJob {
             const float4* r = R.vpl + (size_t)v * 4;
             const float4 r1 = r[1], r2 = r[2];
             Shading vs;
-            vs.x = vx; vs.sN = vn; vs.gN = vn; vs.wo = mk3(r2.x, r2.y, r2.z); vs.tu = r1.w; vs.tv = r2.w; vs.mat = (uint32_t)vmat;
+            vs.x = vx; vs.sN = vn; vs.wo = mk3(r2.x, r2.y, r2.z); vs.tu = r1.w; vs.tv = r2.w; vs.mat = (uint32_t)vmat;
             vs.frame = frame_from(vn);
             vs.albedo = tex_sample(S, S.mats[vs.mat].tex, vs.tu, vs.tv);
             col3 fxi = bsdf_eval(S, vs, -wi);
@@ -1168,9 +1168,9 @@ __global__ void k_debug_bsdf(DScene S, uint32_t mat, const float* wo, const floa
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     Shading sd;
-    sd.x = mk3(0, 0, 0); sd.wo = ld3(wo + i * 3); sd.sN = ld3(n + i * 3); sd.gN = sd.sN;
+    sd.x = mk3(0, 0, 0); sd.wo = ld3(wo + i * 3); sd.sN = ld3(n + i * 3);
     sd.tu = uv[i * 2]; sd.tv = uv[i * 2 + 1]; sd.mat = mat;
-    if ((S.mats[mat].flags & RT_MF_TWOSIDED) && dot3(sd.wo, sd.sN) < 0) { sd.sN = -sd.sN; sd.gN = sd.sN; }
+    if ((S.mats[mat].flags & RT_MF_TWOSIDED) && dot3(sd.wo, sd.sN) < 0) sd.sN = -sd.sN;
     sd.frame = frame_from(sd.sN);
     sd.albedo = tex_sample(S, S.mats[mat].tex, sd.tu, sd.tv);
     if (do_sample) {

@@ -4,7 +4,7 @@
 //   tris     : 64 B / triangle, 64-B aligned, stored in the DFS leaf order of the
 //              reference tree, so "first visited wins ties" (Geometry.h:449) becomes
 //              "lowest index wins".  One lane fetches one record as 4 x dwordx4.
-//   trishade : 64 B / triangle (vertex normals, uvs, area), same order; only read at a hit.
+//   trishade : 64 B / triangle (vertex normals, uvs, material word), same order; only read at a hit.
 //   nodes8   : 80 B per 8-wide node, what the walk reads: derived on the device from nodes2 (walk_tree.hip) by opening the child
 //              with the largest box until eight slots are taken.  Child boxes sit on a 256-step grid of the node's
 //              own box (one byte per plane, rounded outwards), children are numbered consecutively (child_base + rank among
@@ -44,7 +44,7 @@ struct DTri {        // intersection record (Triangle::rayIntersect reads n, d, 
 struct DTriShade {   // shading record (Triangle::interpolateAttributes / sample, Geometry.h:154-174)
     float n0[3], n1[3], n2[3];
     float uv[6];
-    float area;
+    uint32_t mat_gsign;   // DTri::mat_gsign again: a shading point needs the material and nothing else of the intersection record, so it reads this line alone
 };
 // 80 B, five 16-B rows.  Slot s's box is org + q * 2^e per axis, q = byte s of the two plane words (lo rounded down, hi up).
 // meta byte of slot s: 0 = unused; inner child: 0x20 | (24 + s); leaf: (unary triangle count 1 / 3 / 7) << 5 | offset, the
@@ -88,7 +88,7 @@ struct DMaterial {   // 80 B
 
 struct DTexture { uint32_t offset; int32_t width, height; int32_t pad; };  // offset in floats into the texel pool
 
-struct DLight { uint32_t kind; uint32_t tri; };  // kind 0 area (tri = DFS rank), 1 background colour, 2 environment map
+struct DLight { uint32_t kind; uint32_t tri; float area; uint32_t pad; };  // kind 0 area (tri = DFS rank; area = Triangle::area, Geometry.h:80), 1 background colour, 2 environment map
 
 struct DCamera {     // Camera (Scene.h:14-45)
     float P[16], invP[16], cam[16], cam2view[16];

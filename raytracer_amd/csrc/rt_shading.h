@@ -26,7 +26,7 @@ __device__ __forceinline__ f3 to_local(const Frame3& f, f3 a) { return mk3(dot3(
 __device__ __forceinline__ f3 to_world(const Frame3& f, f3 a) { return ((f.u * a.x) + (f.v * a.y)) + (f.w * a.z); }      // Core.h:538
 
 struct Shading {   // ShadingData (Materials.h:14)
-    f3 x, wo, sN, gN;
+    f3 x, wo, sN;
     float tu, tv;
     Frame3 frame;
     uint32_t mat;
@@ -487,18 +487,14 @@ __device__ __forceinline__ f3 tri_sample_point(const TriRows& r, float r1, float
 // Scene::calculateShadingData (Scene.h:185-215) for a hit
 __device__ inline Shading shading_data(const DScene& S, f3 o, f3 dir, float t, float alpha, float beta, uint32_t rank) {
     Shading sd;
-    // of the intersection record only the normal and the material word are needed: its last two rows; the shading record whole
-    const float4* tq = reinterpret_cast<const float4*>(S.tris + rank);
-    const float4 tc = tq[2], te = tq[3];
+    // the shading record whole, and nothing of the intersection record: its material word is repeated here (one cache line per
+    // shading point instead of two).  ShadingData::gNormal (Scene.h:191, :201-203) is not kept: nothing on the path reads it
+    // (Renderer.h:138 is in an unused helper); lights take their triangle's gNormal from the triangle (Lights.h:44-82).
     const float4* sq = reinterpret_cast<const float4*>(S.trishade + rank);
     const float4 s0 = sq[0], s1 = sq[1], s2 = sq[2], s3 = sq[3];
-    const uint32_t mat_gsign = __float_as_uint(te.w);
+    const uint32_t mat_gsign = __float_as_uint(s3.w);
     float gamma = 1.0f - (alpha + beta);
     sd.x = o + (dir * t);
-    {
-        f3 gn = mk3(tc.y, tc.z, tc.w);
-        sd.gN = (mat_gsign & 0x80000000u) ? gn * -1.0f : gn * 1.0f;   // tri_gnormal
-    }
     f3 n = ((mk3(s0.x, s0.y, s0.z) * alpha) + (mk3(s0.w, s1.x, s1.y) * beta)) + (mk3(s1.z, s1.w, s2.x) * gamma);
     sd.sN = norm3(n);
     sd.tu = s2.y * alpha + s2.w * beta + s3.y * gamma;
@@ -507,7 +503,6 @@ __device__ inline Shading shading_data(const DScene& S, f3 o, f3 dir, float t, f
     sd.wo = -dir;
     if (S.mats[sd.mat].flags & RT_MF_TWOSIDED) {
         if (dot3(sd.wo, sd.sN) < 0) sd.sN = -sd.sN;
-        if (dot3(sd.wo, sd.gN) < 0) sd.gN = -sd.gN;
     }
     sd.frame = frame_from(sd.sN);
     sd.albedo = tex_sample(S, S.mats[sd.mat].tex, sd.tu, sd.tv);

@@ -284,7 +284,7 @@ bool host_scene_build(const rt_scene_desc& d, HostScene& hs, std::string& err, D
             DTriShade& s = hs.trishade[r];
             put3(s.n0, n0); put3(s.n1, f3(f[11], f[12], f[13])); put3(s.n2, f3(f[19], f[20], f[21]));
             s.uv[0] = f[6]; s.uv[1] = f[7]; s.uv[2] = f[14]; s.uv[3] = f[15]; s.uv[4] = f[22]; s.uv[5] = f[23];
-            s.area = length(cross(e1, e2)) * 0.5f;
+            s.mat_gsign = o.mat_gsign;
             bounds.grow(p0); bounds.grow(p1); bounds.grow(p2);
             for (int k = 0; k < 3; k++) for (int c = 0; c < 3; c++) amax = std::max(amax, fabsf(f[k * 8 + c]));
         }
@@ -339,9 +339,13 @@ bool host_scene_build(const rt_scene_desc& d, HostScene& hs, std::string& err, D
             total = total / (float)(e.width * e.height);
             power = total * 4.0f * M_PI;
         }
-        if (power > 0) hs.lights.push_back(DLight{ d.background.kind == 0 ? 1u : 2u, 0u });
+        if (power > 0) hs.lights.push_back(DLight{ d.background.kind == 0 ? 1u : 2u, 0u, 0.0f, 0u });
         for (uint32_t t = 0; t < d.n_tris; t++)
-            if (hs.mats[d.tri_material[t]].flags & RT_MF_LIGHT) hs.lights.push_back(DLight{ 0u, rank_of[t] });
+            if (hs.mats[d.tri_material[t]].flags & RT_MF_LIGHT) {
+                const float* f = d.verts + (size_t)t * 24;   // Triangle::init's area (Geometry.h:80), the expression k_records' device twin uses
+                F3 p0 = f3(f[0], f[1], f[2]), p1 = f3(f[8], f[9], f[10]), p2 = f3(f[16], f[17], f[18]);
+                hs.lights.push_back(DLight{ 0u, rank_of[t], length(cross(sub(p2, p1), sub(p0, p2))) * 0.5f, 0u });
+            }
     }
     hs.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return true;
