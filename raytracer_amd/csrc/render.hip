@@ -313,7 +313,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRAV_WAVES) void k_extend(DScene S, RB
 // Material sorting: the hits extend left behind (R.cls per path) are binned into one queue per BSDF class, in
 // queue order, so a shade wave runs one material's code.  Block-lockstep: one atomic per class per 512 paths.
 #define RT_BIN_BLOCK 512
+#ifndef RT_BIN_ITEMS
 #define RT_BIN_ITEMS 4   // paths per thread and block iteration: a block moves 2048 paths per atomic and class
+#endif
 // One contended atomic on a counter costs ~11 ns whatever else the GPU does, so a launch over n paths cannot take less than
 // n / (paths per atomic) x 11 ns per class: with 512 paths per atomic that floor (0.25 ms at 12 M paths) was the kernel's
 // whole duration (PMC: VALU 0.04, TA 0.18 busy).  Slots keep queue order inside the block: (item, wave, lane).
