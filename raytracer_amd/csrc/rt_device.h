@@ -163,16 +163,24 @@ __device__ __forceinline__ bool rt_box_exact(f3 lo, f3 hi, f3 o, f3 inv, float& 
 __device__ __forceinline__ bool rt_ray_is_tame(f3 inv) {
     return (fabsf(inv.x) < 1e18f) && (fabsf(inv.y) < 1e18f) && (fabsf(inv.z) < 1e18f);
 }
-// With RT_NODE_MIX a node step multiplies 1/dir by the node's grid step * 2^24 (rt_node_eval: the plane bytes are read as f16
-// denormals).  A grid step is at most 8/255 of the scene's largest coordinate (k8_emit, walk_tree.hip), so below this bound the
-// scaled factor stays finite (< 5.3e36); a ray above it -- |1/dir| of 1e18 in a scene of 1e13 -- takes the exact walk.  False if
-// the product is inf or NaN.
-__device__ __forceinline__ bool rt_ray_fits_grid(const DScene& S, f3 inv) {
-#if RT_NODE_MIX
-    return fmaxf(fabsf(inv.x), fmaxf(fabsf(inv.y), fabsf(inv.z))) * S.abs_max < 1e31f;
-#else
-    return true;
-#endif
+// Two more conditions a ray must meet to take the wide walk, both relative to the scene's size (M = the largest coordinate
+// in play, scene or origin):
+//  * Upstream accepts a plane hit whose point p = o + dir * t overflows, or whose barycentric products do: u or v come out
+//    NaN and a comparison with NaN rejects nothing (Geometry.h:122-126).  Such a "hit" lies nowhere near its triangle, so the
+//    premise of the conservative culls -- an accepted hit's point is inside every box around its triangle -- does not hold.
+//    For a plane that is not orthogonal to the ray by cancellation, t <= 2 M max|1/dir|, |p| <= 2 M max|dir| max|1/dir| and
+//    the cross products are below 8 M^2 max|dir| max|1/dir|; kept under 1e36 nothing overflows.  Every ray a renderer shoots
+//    in a scene of ordinary size passes (|dir| ~ 1, M ~ 10: up to |1/dir| of 1e18); found by steep rays (a direction component
+//    of 1e-17 beside components of 1e12) on a scene scaled by 1e12.
+//  * With RT_NODE_MIX a node step multiplies 1/dir by the node's grid step * 2^24 (rt_node_eval: the plane bytes are read as
+//    f16 denormals).  A grid step is at most 8/255 of M (k8_emit, walk_tree.hip), so with M max|1/dir| < 1e31 the scaled
+//    factor stays finite (< 5.3e36).
+// A ray that fails either takes the exact walk.  False if a product is inf or NaN.
+__device__ __forceinline__ bool rt_ray_fits_scene(const DScene& S, f3 o, f3 dir, f3 inv) {
+    const float M = fmaxf(S.abs_max, fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))));
+    const float D = fmaxf(fabsf(dir.x), fmaxf(fabsf(dir.y), fabsf(dir.z))), I = fmaxf(fabsf(inv.x), fmaxf(fabsf(inv.y), fabsf(inv.z)));
+    const float IM = I * M;
+    return ((D * IM) * M < 1e36f) && (!RT_NODE_MIX || IM < 1e31f);
 }
 // Beyond that there are rays no renderer shoots but a caller can pass: NaN / inf / 1e38 in the origin or the direction.  Their
 // slab products overflow or are NaN in ways the padded culling was not derived for (it assumes finite arithmetic), so they
@@ -576,7 +584,7 @@ __device__ __forceinline__ bool rt_closest_begin(const DScene& S, f3 o, f3 dir, 
     if (mode == 0 && dir.x == 0.0f && dir.y == 0.0f && dir.z == 0.0f) return true;
     f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
     const bool moderate = rt_ray_is_moderate(o, dir);
-    if (mode == 0 && moderate && rt_ray_is_tame(inv) && rt_ray_fits_grid(S, inv)) { rt_walk_init(S, w, o, dir, inv, 0.0f); return false; }
+    if (mode == 0 && moderate && rt_ray_is_tame(inv) && rt_ray_fits_scene(S, o, dir, inv)) { rt_walk_init(S, w, o, dir, inv, 0.0f); return false; }
     if (COUNT) cexact++;
     if (mode == 0 && moderate) rt_walk_exact<false, COUNT>(S, o, dir, 0.0f, w.best, spill2, gstride, cn, ct);
     else rt_walk_reference<false, COUNT>(S, o, dir, 0.0f, w.best, spill2, gstride, cn, ct);
@@ -595,7 +603,7 @@ __device__ __forceinline__ bool rt_visible_begin(const DScene& S, f3 p1, f3 p2, 
     if (S.root_ref == RT_REF_EMPTY) return true;
     f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
     const bool moderate = rt_ray_is_moderate(o, dir);
-    if (mode == 0 && moderate && rt_ray_is_tame(inv) && rt_ray_fits_grid(S, inv)) { rt_walk_init(S, w, o, dir, inv, maxT); return false; }
+    if (mode == 0 && moderate && rt_ray_is_tame(inv) && rt_ray_fits_scene(S, o, dir, inv)) { rt_walk_init(S, w, o, dir, inv, maxT); return false; }
     if (COUNT) cexact++;
     HitRec dummy;
     visible = (mode == 0 && moderate) ? rt_walk_exact<true, COUNT>(S, o, dir, maxT, dummy, spill2, gstride, cn, ct)

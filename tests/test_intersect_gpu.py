@@ -317,11 +317,16 @@ def test_answers_refused_by_the_gate_box_are_recomputed_exactly(make):
     sc.close()
 
 
-@pytest.mark.parametrize("scale,shift", [(1e-12, 0.0), (1e12, 0.0), (1.0, 3e5), (1e-3, 40.0)], ids=["tiny", "huge", "far-from-origin", "small-and-offset"])
+@pytest.mark.parametrize("scale,shift", [(1e-12, 0.0), (1e12, 0.0), (1.0, 3e5), (1e-3, 40.0), (1e15, 0.0)],
+                         ids=["tiny", "huge", "far-from-origin", "small-and-offset", "beyond-the-scaled-step"])
 def test_quantised_nodes_on_scaled_and_shifted_scenes(scale, shift):
     """The walk's nodes put child boxes on a 256-step grid whose step is a power of two taken from the node's extent: scenes a
     factor 1e12 smaller or larger than the fixtures, or far from the origin (where a coordinate's ulp approaches the size of a
-    triangle), must give the oracle's answers bit for bit, and a flat scene (zero extent on an axis: step 0) too."""
+    triangle), must give the oracle's answers bit for bit, and a flat scene (zero extent on an axis: step 0) too.  The node step
+    multiplies 1/dir by the grid step * 2^24 (plane bytes read as f16 denormals): rays with a direction component of 1e-17 keep
+    that product finite at every scale but 1e15, where |1/dir| * the largest coordinate passes 1e31; and beside components of the
+    scene's size they make upstream's own arithmetic overflow on the large scenes (see below).  Either way they must take the
+    exact walk (rt_ray_fits_scene) -- the counters say that they do."""
     base = scenes.random_soup(4000, seed=12)
     v = base.verts.copy()
     v[:, :, :3] = (v[:, :, :3] * np.float32(scale) + np.float32(shift)).astype(np.float32)
@@ -331,8 +336,19 @@ def test_quantised_nodes_on_scaled_and_shifted_scenes(scale, shift):
     scenes.set_camera(s, (c, c, c + 12 * scale), (c, c, c), (0, 1, 0), 45.0, 64, 64)
     o, sc = orc.OracleScene(s), api.Scene(s)
     rays, segs = aimed_rays(s, 150_000, seed=3)
-    rays = np.concatenate([rays, scenes.primary_rays(s, 20_000, 1), axis_rays(s, 10_000)])
-    assert_hits_bitexact(sc.traverse(rays, 0), o.traverse(rays, threads=8), f"scaled x{scale} +{shift}")
+    steep = rays[:5000].copy()                             # one direction component tiny but not zero: |1/dir| = 1e17, a tame ray
+    steep[np.arange(5000), 3 + np.arange(5000) % 3] = np.where(np.arange(5000) % 2 == 0, 1e-17, -1e-17).astype(np.float32)
+    rays = np.concatenate([rays, scenes.primary_rays(s, 20_000, 1), axis_rays(s, 10_000), steep])
+    sc.counters_enable(True); sc.counters()
+    # nan_payload_free: at 1e12 upstream accepts eleven of the steep rays' plane hits at t ~ 1e28 with NaN barycentrics (their
+    # points overflow; a comparison with NaN rejects nothing) -- the GPU must report the same hits (rt_ray_fits_scene sends such
+    # rays to the exact walk), and 1 - (NaN + NaN) carries another payload on x86 than on the GPU
+    assert_hits_bitexact(sc.traverse(rays, 0), o.traverse(rays, threads=8), f"scaled x{scale} +{shift}", nan_payload_free=True)
+    exact = sc.counters()["exact_path_rays"]
+    sc.counters_enable(False)
+    print(f"scale {scale}: {exact} of {len(rays)} rays took an exact walk")
+    if scale >= 1e12:
+        assert exact >= 5000, "rays whose scaled grid step or whose hit points can overflow must take the exact walk"
     assert (sc.visible(segs, 0) == o.visible(segs, threads=8)).all()
     q, _, _ = sc.walk_nodes()
     assert np.isfinite(q["org"]).all() and (q["exp"] >= -126).all()
