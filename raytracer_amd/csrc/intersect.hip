@@ -163,6 +163,14 @@ int device_scene_build(const rt_scene_desc& d, HostScene& hs, DeviceGeometry& ou
 
 static int na_scratch_setup(int device);   // scratch of the no-allocation entry point (below)
 
+// DScene::tri_cls: one byte per triangle (DFS rank) with what ExtendJob::retire needs of the hit's material
+__global__ void k_tri_class(uint32_t n, const DTri* __restrict__ tris, const DMaterial* __restrict__ mats, uint8_t* __restrict__ out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const DMaterial& m = mats[tris[r].mat_gsign & 0x7FFFFFFFu];
+    out[r] = (uint8_t)((uint32_t)rt_class_of(m.type) | ((m.flags & RT_MF_LIGHT) ? 0x80u : 0u));
+}
+
 extern "C" int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) { return rt_scene_create_ex(desc, 0u, out); }
 
 extern "C" int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_scene** out) {
@@ -198,6 +206,15 @@ extern "C" int rt_scene_create_ex(const rt_scene_desc* desc, uint32_t flags, rt_
     if (!h.env_cond.empty() && ((rc = upload(s, h.env_cond, &d.env_cond)) || (rc = upload(s, h.env_marg, &d.env_marg)))) return fail(rc);
     d.n_tris = h.n_tris; d.n_lights = (uint32_t)h.lights.size();
     d.n_nodes2 = h.n_nodes2;
+    {
+        void* pc = nullptr;
+        if (hipMalloc(&pc, h.n_tris ? h.n_tris : 16) != hipSuccess) { rt_set_error("rt_scene_create: out of device memory (triangle classes)"); return fail(RT_ERR_NOMEM); }
+        s->allocs.push_back(pc); s->device_bytes += h.n_tris; d.tri_cls = (const uint8_t*)pc;
+        if (h.n_tris) {
+            hipLaunchKernelGGL(k_tri_class, dim3((h.n_tris + 255) / 256), dim3(256), 0, 0, h.n_tris, d.tris, d.mats, (uint8_t*)pc);
+            if (hipGetLastError() != hipSuccess) { rt_set_error("rt_scene_create: k_tri_class launch failed"); return fail(RT_ERR_DEVICE); }
+        }
+    }
     // the walk's own arrays (gate boxes, 8-wide nodes, walk-ordered triangle records), derived on the device from whichever
     // builder made tris + nodes2 (walk_tree.hip)
     if ((rc = rt_build_walk_tree(s))) return fail(rc);

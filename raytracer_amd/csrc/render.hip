@@ -18,6 +18,9 @@
 #include "scene_dev.h"
 
 #define RT_NCLASS 6
+#ifndef RT_TRI_CLS
+#define RT_TRI_CLS 1   // ExtendJob::retire files a hit by DScene::tri_cls (0: by the hit's tris record and its material)
+#endif
 #define RT_FLAG_CANHIT 0x100u
 #define RT_FLAG_DEAD 0x200u
 
@@ -146,16 +149,7 @@ __device__ __forceinline__ bool slot_pixel(const RBuf& R, uint32_t q, uint32_t& 
     y = (tile / R.tiles_x) * 8 + (in >> 3);
     return x < R.w && y < R.h;
 }
-__device__ __forceinline__ int class_of(uint32_t type) {
-    switch (type) {
-    case RT_MAT_MIRROR: return 1;
-    case RT_MAT_GLASS: return 2;
-    case RT_MAT_CONDUCTOR: return 3;
-    case RT_MAT_DIELECTRIC: return 4;
-    case RT_MAT_PLASTIC: return 5;
-    default: return 0;  // diffuse, oren-nayar
-    }
-}
+__device__ __forceinline__ int class_of(uint32_t type) { return rt_class_of(type); }
 __device__ __forceinline__ f3 mul_point(const float* m, f3 v) {  // Core.h:302
     return mk3((v.x * m[0] + v.y * m[1] + v.z * m[2]) + m[3], (v.x * m[4] + v.y * m[5] + v.z * m[6]) + m[7],
                (v.x * m[8] + v.y * m[9] + v.z * m[10]) + m[11]);
@@ -268,18 +262,25 @@ struct ExtendJob {
         uint32_t path = path_of(i);
         uint32_t cls = RT_CLS_NONE;
         if (h.t < RT_FLT_MAX) {
-            uint32_t mat = S.tris[h.rank].mat_gsign & 0x7FFFFFFFu;
-            const DMaterial& m = S.mats[mat];
-            if (!LT && (m.flags & RT_MF_LIGHT)) {
+#if RT_TRI_CLS
+            const uint32_t tc = S.tri_cls[h.rank];   // class | emitter bit: a byte of a 1-B-per-triangle array instead of a line of tris and one of mats
+            const bool is_light = (tc & 0x80u) != 0u;
+#else
+            const DMaterial& m0 = S.mats[S.tris[h.rank].mat_gsign & 0x7FFFFFFFu];
+            const uint32_t tc = (uint32_t)class_of(m0.type);
+            const bool is_light = (m0.flags & RT_MF_LIGHT) != 0u;
+#endif
+            if (!LT && is_light) {
                 float4 th = R.st[(size_t)path * 4 + 3];
                 if (__float_as_uint(th.w) & RT_FLAG_CANHIT) {
+                    const DMaterial& m = S.mats[S.tris[h.rank].mat_gsign & 0x7FFFFFFFu];
                     float4 L = R.rad[path];
                     col3 c = mkc(th.x, th.y, th.z) * mat_emission(m);
                     R.rad[path] = make_float4(L.x + c.r, L.y + c.g, L.z + c.b, L.w);
                 }
             } else {
                 R.st[(size_t)path * 4 + 2] = make_float4(h.t, h.u, h.v, __uint_as_float(h.rank));
-                cls = LT ? 0u : (uint32_t)class_of(m.type);
+                cls = LT ? 0u : (tc & 0x7Fu);
             }
         } else if (!LT) {
             float4 L = R.rad[path];

@@ -85,6 +85,20 @@ struct DMaterial {   // 80 B
 #define RT_MF_TWOSIDED 1u
 #define RT_MF_SPECULAR 2u
 #define RT_MF_LIGHT 4u
+// BSDF class of a material type (rtamd.h's RT_MAT_* order): the queues k_shade walks are sorted by it, so that a wave runs one BSDF's code
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int rt_class_of(uint32_t type) {
+    switch (type) {
+    case 1: return 1;   // RT_MAT_MIRROR
+    case 3: return 2;   // RT_MAT_GLASS
+    case 2: return 3;   // RT_MAT_CONDUCTOR
+    case 4: return 4;   // RT_MAT_DIELECTRIC
+    case 6: return 5;   // RT_MAT_PLASTIC
+    default: return 0;  // diffuse, Oren-Nayar
+    }
+}
 
 struct DTexture { uint32_t offset; int32_t width, height; int32_t pad; };  // offset in floats into the texel pool
 
@@ -109,6 +123,8 @@ struct DScene {
     const DTexture* tex;
     const float* texels;
     const DLight* lights;
+    const uint8_t* tri_cls;   // per DFS rank: the BSDF class of the triangle's material (rt_class_of), 0x80 for an emitter -- what a closest-hit walk needs to
+                              // file its hit, from a 1-B-per-triangle array that stays in L2 instead of a line of `tris` and one of the material table
     uint32_t n_tris, n_lights, n_nodes2, n_nodes8;
     uint32_t root_ref;        // RT_REF_EMPTY for an empty scene, else node 0
     uint32_t walk_stack, max_stack2;   // most 8-byte entries a walk over nodes8 can have waiting; most words of the reference-order walk
