@@ -57,6 +57,8 @@ def main():
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} needs WORLD_SIZE={a.gpus} (launch with torch.distributed.run); got {world}")
 
+    # the host driver only supports dmabuf IPC: RCCL's buffer registration across ranks needs this before the HIP runtime starts
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
@@ -71,7 +73,6 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearse:
             dist.init_process_group("gloo")
         else:
