@@ -150,6 +150,8 @@ __device__ __forceinline__ bool slot_pixel(const RBuf& R, uint32_t q, uint32_t& 
     return x < R.w && y < R.h;
 }
 __device__ __forceinline__ int class_of(uint32_t type) { return rt_class_of(type); }
+static_assert(RT_MAT_MIRROR == 1 && RT_MAT_CONDUCTOR == 2 && RT_MAT_GLASS == 3 && RT_MAT_DIELECTRIC == 4 && RT_MAT_PLASTIC == 6,
+              "rt_class_of (rt_common.h) switches on rtamd.h's RT_MAT_* values");
 __device__ __forceinline__ f3 mul_point(const float* m, f3 v) {  // Core.h:302
     return mk3((v.x * m[0] + v.y * m[1] + v.z * m[2]) + m[3], (v.x * m[4] + v.y * m[5] + v.z * m[6]) + m[7],
                (v.x * m[8] + v.y * m[9] + v.z * m[10]) + m[11]);
