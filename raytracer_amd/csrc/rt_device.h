@@ -539,6 +539,10 @@ __device__ __forceinline__ bool rt_wide_step(const DScene& S, Walk& w, TravStack
 #define RT_VOTE_NUM 1
 #define RT_VOTE_DEN 2
 #endif
+#ifndef RT_VOTE_NUM_ANY   // any-hit walks on their own: 1:1 / 1:2 / 1:3 give k_connect 12.95 / 12.75 / 13.2 ms per 20 spp; stealing every step / every fourth: no change
+#define RT_VOTE_NUM_ANY RT_VOTE_NUM
+#define RT_VOTE_DEN_ANY RT_VOTE_DEN
+#endif
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ bool rt_vote_step(const DScene& S, Walk& w, bool busy, TravStack& st, uint32_t& c_nodes, uint32_t& c_tris) {
     // a lane without a walk holds cm == 0 and pm == 0 (rt_persistent_walk clears them at the start, a walk leaves them so
@@ -548,7 +552,7 @@ __device__ __forceinline__ bool rt_vote_step(const DScene& S, Walk& w, bool busy
     const bool innode = rt_cur_is_nodes(w);
     const bool inleaf = w.pm != 0u;
     const int nl = __builtin_popcountll(rt_ballot(inleaf)), nn = __builtin_popcountll(rt_ballot(innode));
-    if (nn * RT_VOTE_NUM >= nl * RT_VOTE_DEN) {
+    if (nn * (ANY ? RT_VOTE_NUM_ANY : RT_VOTE_NUM) >= nl * (ANY ? RT_VOTE_DEN_ANY : RT_VOTE_DEN)) {
 #ifdef RT_DBG_WAVESTEPS
         if (COUNT) c_nodes++;
 #endif
