@@ -647,7 +647,11 @@ struct CameraJob {
         f3 cd = norm3(p - org);
         float costheta = dot3(ld3(cam.view_dir), cd);
         if (costheta <= 0) return;
-        float we = (float)(1.f / (cam.Afilm * pow((double)costheta, 4.0)));
+        // std::pow(costheta, 4) (Renderer.h:688) is pow(double, double).  A float's square is exact in double (48 bits) and the
+        // square of that rounds once: the correctly rounded cos^4, which is what glibc's pow returns -- without the device
+        // library's pow in a traversal kernel (it cost k_connect_camera 124-188 B of scratch)
+        const double c2 = (double)costheta * (double)costheta;
+        float we = (float)(1.f / (cam.Afilm * (c2 * c2)));
         float4 c = e[2];
         if (FILTERED) { film_splat(film, cam, F, x, y, mkc(c.x * we, c.y * we, c.z * we)); return; }
         int px = (int)x, py = (int)y;  // Film::splat with BoxFilter (Imaging.h:224)
