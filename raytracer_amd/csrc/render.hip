@@ -969,6 +969,7 @@ __global__ __launch_bounds__(RT_LT_BLOCK) void k_lt_generate(DScene S, RBuf R, C
             if (ok) {
                 R.st[(size_t)i * 4 + 0] = make_float4(p.x, p.y, p.z, __uint_as_float(rng.key));
                 R.st[(size_t)i * 4 + 1] = make_float4(wi.x, wi.y, wi.z, __uint_as_float(rng.ctr));
+                R.st[(size_t)i * 4 + 2] = make_float4(0, 0, 0, 0);   // the hit row too: a whole 64-B record per lane, no partial line for the memory side to merge
                 R.st[(size_t)i * 4 + 3] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(0u));
                 R.rad[i] = make_float4(Le.r, Le.g, Le.b, 0);
             } else R.st[(size_t)i * 4 + 3] = make_float4(0, 0, 0, __uint_as_float(RT_FLAG_DEAD));

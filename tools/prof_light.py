@@ -1,4 +1,4 @@
-"""Per-kernel times (HIP events) of light tracing on the bench scene.  Usage: python tools/prof_light.py [spp]"""
+"""Per-kernel times (HIP events) of light tracing on the bench scene.  Usage: python tools/prof_light.py [spp [streams]]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracer_amd import api, scenes
@@ -10,6 +10,8 @@ rt.render(api.LIGHT, spp, 1, 0); rt.sync(); rt.clear(); rt.counters(reset=True)
 t = time.perf_counter(); rt.render(api.LIGHT, spp, 1, 100); rt.sync(); dt = time.perf_counter() - t
 c = rt.counters(reset=True)
 print(f"unprofiled: {dt*1e3/spp:.3f} ms/spp, {(c['closest_rays']+c['any_rays'])/dt/1e6:.1f} Mrays/s, closest {c['closest_rays']/spp/1e6:.2f} M/spp any {c['any_rays']/spp/1e6:.2f} M/spp")
+if len(sys.argv) > 2: rt.set_streams(int(sys.argv[2]))   # 1: every kernel alone on the GPU (unshared durations)
+rt.render(api.LIGHT, spp, 1, 150); rt.sync()
 rt.profile_enable(True); rt.profile(reset=True)
 t = time.perf_counter(); rt.render(api.LIGHT, spp, 1, 200); rt.sync(); dt = time.perf_counter() - t
 print(f"profiled: {dt*1e3/spp:.3f} ms/spp")
