@@ -137,6 +137,9 @@ int rt_scene_debug_ref_nodes(rt_scene* scene, void* out, size_t max_nodes);
  * leaf order: the reference box whose rayAABB (Geometry.h:207) decides whether upstream tests that triangle) and the triangle records in the
  * order the 8-wide tree names them (n_tris x 64 B: v0 v1 v2 n d 1/area rank material).  Any pointer may be NULL. */
 int rt_scene_debug_walk_nodes(rt_scene* scene, void* nodes_out, size_t max_nodes, void* gate_out, size_t max_tris, void* trisw_out);
+/* One byte per triangle in DFS leaf order: the BSDF class the renderer files a hit on it under (0 diffuse / Oren-Nayar, 1 mirror, 2 glass,
+ * 3 conductor, 4 dielectric, 5 plastic) | 0x80 for an emitter (csrc/rt_common.h DScene::tri_cls); no counterpart upstream, for tests. */
+int rt_scene_debug_tri_classes(rt_scene* scene, uint8_t* out, size_t max_tris);
 /* Host-only structure query: runs the same builder without touching a device (leaf_order/info may be NULL).
  * Not a compute path: nothing can be traversed or rendered without a GPU. */
 int rt_host_build_info(const rt_scene_desc* desc, uint32_t* leaf_order, rt_scene_info* info);

@@ -63,7 +63,7 @@ SYMBOLS = [
     "rt_film_set_spp", "rt_vpl_trace", "rt_vpl_count", "rt_render_counters", "rt_renderer_sync", "rt_film_save_hdr",
     "rt_film_tonemap", "rt_profile_enable", "rt_profile_read", "rt_debug_bsdf_sample", "rt_debug_bsdf_eval", "rt_debug_rng", "rt_matrix_invert", "rt_scene_create_ex",
     "rt_renderer_set_filter", "rt_render_aov", "rt_intersect_closest_noalloc", "rt_renderer_set_streams", "rt_debug_env", "rt_scene_debug_ref_nodes",
-    "rt_scene_debug_walk_nodes",
+    "rt_scene_debug_walk_nodes", "rt_scene_debug_tri_classes",
 ]
 
 
@@ -98,6 +98,7 @@ def lib():
         _sig(L, "rt_scene_leaf_order", [vp, vp])
         _sig(L, "rt_scene_debug_ref_nodes", [vp, vp, sz])
         _sig(L, "rt_scene_debug_walk_nodes", [vp, vp, sz, vp, sz, vp])
+        _sig(L, "rt_scene_debug_tri_classes", [vp, vp, sz])
         _sig(L, "rt_host_build_info", [C.POINTER(SceneDesc), vp, C.POINTER(SceneInfo)])
         _sig(L, "rt_intersect_closest", [vp, vp, sz, vp, i32])
         _sig(L, "rt_intersect_closest_dev", [vp, vp, sz, vp, i32, vp])
@@ -217,6 +218,12 @@ class Scene:
         trisw = np.zeros(self.ntris, WALK_TRI_DTYPE)
         _check(self.L.rt_scene_debug_walk_nodes(self.h, nodes.ctypes.data, n, gate.ctypes.data, self.ntris, trisw.ctypes.data), "rt_scene_debug_walk_nodes")
         return nodes, gate, trisw
+
+    def tri_classes(self):
+        """One byte per triangle (DFS leaf order): BSDF class | 0x80 for an emitter, as ExtendJob::retire reads it."""
+        out = np.zeros(self.ntris, np.uint8)
+        _check(self.L.rt_scene_debug_tri_classes(self.h, out.ctypes.data, self.ntris), "rt_scene_debug_tri_classes")
+        return out
 
     # Scene::traverse (Scene.h:118)
     def traverse(self, rays, mode=0):

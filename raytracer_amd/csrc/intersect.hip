@@ -297,6 +297,12 @@ extern "C" int rt_scene_debug_walk_nodes(rt_scene* s, void* nodes_out, size_t ma
     if (trisw_out && s->host.n_tris) RT_HIP(hipMemcpy(trisw_out, s->d.trisw, (size_t)s->host.n_tris * sizeof(DTri), hipMemcpyDeviceToHost));
     return RT_OK;
 }
+extern "C" int rt_scene_debug_tri_classes(rt_scene* s, uint8_t* out, size_t max_tris) {
+    if (!s || !out) { rt_set_error("rt_scene_debug_tri_classes: NULL argument"); return RT_ERR_INVALID; }
+    if (max_tris < s->host.n_tris) { rt_set_error("rt_scene_debug_tri_classes: buffer too small"); return RT_ERR_INVALID; }
+    if (s->host.n_tris) RT_HIP(hipMemcpy(out, s->d.tri_cls, (size_t)s->host.n_tris, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
 extern "C" int rt_scene_leaf_order(const rt_scene* s, uint32_t* out) {
     if (!s || !out) { rt_set_error("rt_scene_leaf_order: NULL argument"); return RT_ERR_INVALID; }
     memcpy(out, s->host.leaf_order.data(), s->host.leaf_order.size() * sizeof(uint32_t));

@@ -57,6 +57,11 @@ def test_device_build_equals_host_build(make):
         assert ih[k] == idv[k], k
     assert np.array_equal(h.leaf_order(), d.leaf_order())
     assert same_walk_nodes(h, d) == ih["wide_nodes"]
+    # the byte per triangle a closest-hit walk files its hit by: BSDF class of the triangle's material, 0x80 for an emitter
+    cls_of = {scenes.DIFFUSE: 0, scenes.ORENNAYAR: 0, scenes.MIRROR: 1, scenes.GLASS: 2, scenes.CONDUCTOR: 3, scenes.DIELECTRIC: 4, scenes.PLASTIC: 5}
+    per_mat = np.array([cls_of[m.type] | (0x80 if max(m.emission) > 0 else 0) for m in s.materials], np.uint8)
+    want_cls = per_mat[s.tri_mat[d.leaf_order()]]
+    assert np.array_equal(d.tri_classes(), want_cls) and np.array_equal(h.tri_classes(), want_cls)
     rays = np.concatenate([scenes.bounce_rays(s, 100000, 5), scenes.primary_rays(s, 50000, 6) if s.cam_P is not None else scenes.bounce_rays(s, 50000, 7)])
     for mode in (0, 1):
         a, b = h.traverse(rays, mode), d.traverse(rays, mode)
