@@ -659,7 +659,7 @@ __device__ __forceinline__ void rt_settle(const DScene& S, Walk& w, bool& visibl
 #define RT_REFILL_IDLE 32
 #endif
 #ifndef RT_REFILL_IDLE_ANY
-#define RT_REFILL_IDLE_ANY RT_REFILL_IDLE
+#define RT_REFILL_IDLE_ANY 24   // any-hit walks: 32 / 24 / 16 / 12 idle lanes give k_connect 12.75 / 12.6 / 12.5 / 12.6 ms per 20 spp (closest-hit walks: 32 / 24 / 16: 25.1 / 25.15 / 25.5)
 #endif
 
 // Tail: once the source is drained a wave is left with its slowest walks -- a few rays that take 1000+ steps where the mean
@@ -689,15 +689,33 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
     bool busy = false, done = false, visible = true;
     uint32_t pb = 0, pe = 0;   // the wave's pool of granted items (wave-uniform)
     bool drained = false;      // wave-uniform
+#ifdef RT_DBG_PHASE
+    // Debug build: where a wave's time goes -- shader cycles inside the retire / refill branch (settle + retire, the work atomic,
+    // load + begin) against all cycles of the main loop, reported through the counters of a counting pass (tools/dbg_phase.py):
+    // lane_busy / lane_slots = the refill share, nodes / tris = its first two parts.  Bench frame: 0.39 of a k_extend wave's time
+    // (0.21 settle + retire, 0.07 work atomic, 0.12 load + begin), 0.40 of a k_connect wave's -- all of it memory latency, which
+    // the other four waves of the SIMD cover: issuing the new items' first loads before the retire (bit-exact, built and
+    // measured) changed nothing, nor does refilling at 24 or 16 idle lanes (lane occupancy 0.71 -> 0.76 -> 0.81, same time).
+    unsigned long long ph_all = clock64(), ph_ref = 0, ph_t0 = 0, ph_t1 = 0, ph_ret = 0, ph_nxt = 0;
+#endif
     for (;;) {
         unsigned long long idle = rt_ballot(!busy);
         uint32_t nidle = (uint32_t)__popcll(idle);
         if (drained ? (nidle == 64u) : (nidle >= (uint32_t)(ANY ? RT_REFILL_IDLE_ANY : RT_REFILL_IDLE))) {
+#ifdef RT_DBG_PHASE
+            ph_t0 = clock64();
+#endif
             if (done) { rt_settle<ANY, COUNT>(S, w, visible, spill2, gstride, cn, ct, c_refused); job.retire(item, w, visible); done = false; }
+#ifdef RT_DBG_PHASE
+            { const unsigned long long t1_ = clock64(); ph_ret += t1_ - ph_t0; ph_t1 = t1_; }
+#endif
             if (drained) break;
             if (pb >= pe) {
                 if (!src.next(pb, pe)) { drained = true; if (RT_TAIL_STEAL) break; continue; }
             }
+#ifdef RT_DBG_PHASE
+            ph_nxt += clock64() - ph_t1;
+#endif
             uint32_t take = pe - pb;
             take = take < nidle ? take : nidle;
             uint32_t my = (uint32_t)__popcll(idle & ((1ULL << lane) - 1ULL));
@@ -712,6 +730,9 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
                 }
             }
             pb += take;
+#ifdef RT_DBG_PHASE
+            ph_ref += clock64() - ph_t0;
+#endif
             continue;  // re-count: short grants and dead items leave lanes idle
         }
 #pragma unroll
@@ -723,6 +744,14 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
             }
         }
     }
+#ifdef RT_DBG_PHASE
+    ph_all = clock64() - ph_all;
+    if (COUNT && (threadIdx.x & 63) == 0) {
+        c_slots = 0; c_busy = 0; cn = 0; ct = 0;
+        atomicAdd(ANY ? &counters->any_slots : &counters->slots, ph_all >> 6); atomicAdd(ANY ? &counters->any_busy : &counters->busy, ph_ref >> 6);
+        atomicAdd(ANY ? &counters->any_nodes : &counters->nodes, ph_ret >> 6); atomicAdd(ANY ? &counters->any_tris : &counters->tris, ph_nxt >> 6);
+    }
+#endif
     if (RT_TAIL_STEAL) {
         // Every lane is busy (walking its own item) or free here: finished lanes retired above.  From now on an item can be in
         // several lanes at once.  It keeps one record in LDS, in the slot of the lane that held it when the tail began (`own`):
