@@ -58,6 +58,7 @@ struct ClosestJob {
     const float* __restrict__ rays;
     rt_hit* __restrict__ out;
     uint32_t done;
+    static constexpr uint32_t refill_idle = RT_REFILL_IDLE;
     __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d) {
         const float* r = rays + (size_t)i * 6;
         o = mk3(r[0], r[1], r[2]); d = mk3(r[3], r[4], r[5]);
@@ -77,6 +78,7 @@ struct AnyJob {
     const float* __restrict__ segs;
     uint8_t* __restrict__ out;
     uint32_t done;
+    static constexpr uint32_t refill_idle = RT_REFILL_IDLE_ANY;
     __device__ __forceinline__ bool load(uint32_t i, f3& p1, f3& p2) {
         const float* q = segs + (size_t)i * 6;
         p1 = mk3(q[0], q[1], q[2]); p2 = mk3(q[3], q[4], q[5]);

@@ -251,6 +251,7 @@ struct ExtendJob {
     const RBuf& R;
     const uint32_t* queue;
     int first;
+    static constexpr uint32_t refill_idle = RT_REFILL_IDLE;
     __device__ __forceinline__ uint32_t path_of(uint32_t i) const { return first ? i : queue[i]; }
     __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d) {
         uint32_t path = path_of(i);
@@ -512,6 +513,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_OCC) void k_shade(DScene S
 struct ConnectJob {
     const RBuf& R;
     const bool nf;   // some request of this launch has a non-finite throughput channel (Ctl::nf_shadow)
+    static constexpr uint32_t refill_idle = RT_REFILL_IDLE_ANY;
     __device__ __forceinline__ bool load(uint32_t i, f3& p1, f3& p2) {
         const float4* e = R.shadow + (size_t)i * 3;
         float4 a = e[0], b = e[1];
@@ -628,6 +630,7 @@ struct CameraJob {
     const RBuf& R;
     float* film;
     const DFilter& F;
+    static constexpr uint32_t refill_idle = RT_REFILL_IDLE;
     __device__ __forceinline__ bool load(uint32_t i, f3& p1, f3& p2) {
         float4 a = R.shadow[(size_t)i * 3];
         float x, y;
@@ -1098,6 +1101,7 @@ struct GatherJob {
     const RBuf& R;
     uint32_t n, v0;
     unsigned long long nrays;
+    static constexpr uint32_t refill_idle = RT_REFILL_IDLE;
     __device__ __forceinline__ bool terms(uint32_t k, Shading& sd, f3& vx, f3& vn, f3& wi, float& G, float4& r0, float4& r3, col3& T, uint32_t& path, uint32_t& v) const {
         v = v0 + k / n;
         const uint32_t i = k - (k / n) * n;

@@ -646,7 +646,8 @@ __device__ __forceinline__ void rt_settle(const DScene& S, Walk& w, bool& visibl
 // number of live lanes per VALU instruction at ~11 of 64 that way.  Here a wave keeps a private pool of item
 // indices (one work atomic per grant of 64-256 items); whenever at least RT_REFILL_IDLE lanes are idle the finished
 // lanes retire their result together and every idle lane is handed the next item of the pool.
-//   Job:    bool load(uint32_t item, f3& a, f3& b)   -- closest: origin, direction; any: p1, p2.  false = nothing to trace
+//   Job:    static constexpr uint32_t refill_idle    -- idle lanes at which the wave retires and refills
+//           bool load(uint32_t item, f3& a, f3& b)   -- closest: origin, direction; any: p1, p2.  false = nothing to trace
 //           void retire(uint32_t item, const Walk& w, bool visible)
 //   Source: bool next(uint32_t& begin, uint32_t& end) -- wave-uniform grant of items [begin, end), false when drained
 // Which lane traces which item only affects speed: every item is loaded, traced and retired by exactly one lane.
@@ -658,9 +659,10 @@ __device__ __forceinline__ void rt_settle(const DScene& S, Walk& w, bool& visibl
 #ifndef RT_REFILL_IDLE
 #define RT_REFILL_IDLE 32
 #endif
+// A job names its own threshold (Job::refill_idle): the cheaper its load and retire, the earlier a refill pays.
 #ifndef RT_REFILL_IDLE_ANY
-#define RT_REFILL_IDLE_ANY 24   // any-hit walks: 32 / 24 / 16 / 12 idle lanes give k_connect 12.75 / 12.6 / 12.5 / 12.6 ms per 20 spp (closest-hit walks: 32 / 24 / 16: 25.1 / 25.15 / 25.5)
-#endif
+#define RT_REFILL_IDLE_ANY 24   // k_connect (NEE shadow rays): 32 / 24 / 16 / 12 idle lanes give 12.75 / 12.6 / 12.5 / 12.6 ms per 20 spp (closest-hit walks: 32 / 24 / 16: 25.1 / 25.15 / 25.5);
+#endif                          // k_gather and k_connect_camera, whose retire shades, lose at 24 (instant radiosity 4680 -> 4555 Mrays/s) and stay at RT_REFILL_IDLE
 
 // Tail: once the source is drained a wave is left with its slowest walks -- a few rays that take 1000+ steps where the mean
 // is 25 -- and the launch lasts until they end.  From then on idle lanes take work from busy ones: every RT_STEAL_EVERY steps
@@ -701,7 +703,7 @@ __device__ __forceinline__ void rt_persistent_walk(const DScene& S, Job& job, So
     for (;;) {
         unsigned long long idle = rt_ballot(!busy);
         uint32_t nidle = (uint32_t)__popcll(idle);
-        if (drained ? (nidle == 64u) : (nidle >= (uint32_t)(ANY ? RT_REFILL_IDLE_ANY : RT_REFILL_IDLE))) {
+        if (drained ? (nidle == 64u) : (nidle >= (uint32_t)Job::refill_idle)) {
 #ifdef RT_DBG_PHASE
             ph_t0 = clock64();
 #endif
