@@ -150,8 +150,10 @@ int rt_host_build_info(const rt_scene_desc* desc, uint32_t* leaf_order, rt_scene
 int rt_matrix_invert(const float* m16, float* out16);
 
 /* --- IntersectionData Scene::traverse(const Ray&) (Scene.h:118), batched.
- * `mode`: 0 = 8-wide conservative walk + gate-box check (+ reference-order fallback for rays with a zero/denormal
- * direction component), 1 = reference-order walk for every ray (validation).
+ * `mode`: 0 = 8-wide conservative walk + gate-box check; rays outside its domain take an exact walk over upstream's own boxes (a zero /
+ * denormal direction component, NaN / inf / >= 1e18 anywhere, or -- relative to the scene's largest coordinate M -- M max|1/dir| >= 1e31 or
+ * M^2 max|dir| max|1/dir| >= 1e36, where upstream's own hit-point arithmetic can overflow): the answers are upstream's either way, only the
+ * speed differs.  1 = reference-order walk for every ray (validation).
  * Host-buffer form copies in/out; the _dev form takes device pointers and a hipStream_t. */
 int rt_intersect_closest(rt_scene* scene, const rt_ray* rays, size_t n, rt_hit* out, int mode);
 int rt_intersect_closest_dev(rt_scene* scene, const rt_ray* d_rays, size_t n, rt_hit* d_out, int mode, void* stream);
